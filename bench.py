@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py — the hot-path benchmark (BASELINE.json metric: GFLOP/s at 5*N*log2(N) flops per transform,
+plus the HBM roofline fraction of the dominant kernel).
+
+Workload at N=1 GPU = BASELINE.json configs[1]: batched power-of-two N = 2^20 Complex<f32>, batch = 1024,
+forward + inverse, device-resident (inputs in HBM when the timed region starts).  One "step" = one
+forward and one inverse pass of Fft::process over the whole batch.  With --gpus G every rank owns its
+own 1024-transform shard (weak scaling, no data-path collective; the batch dimension is the shard axis).
+
+Methodology mirrors benches/bench_rustfft.rs:43-54 of the reference: plan once, allocate once, time
+only the process calls.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(n, log):
+    """Oracle (C++ restatement of RustFFT's scalar path, kind="port") timed on this box's host cores:
+    every core owns a slice of the sample batch and shares one plan (examples/concurrency.rs:9-30)."""
+    import numpy as np
+
+    from oracle import rustfft_oracle as oracle
+
+    oracle.build()
+    cores = os.cpu_count() or 1
+    fwd, inv = oracle.plan(np.complex64, n, 0), oracle.plan(np.complex64, n, 1)
+    rng = np.random.default_rng(1)
+    one = (rng.uniform(0, 10, n) + 1j * rng.uniform(0, 10, n)).astype(np.complex64)
+    t1 = fwd.time_batch(one.copy(), 1, 1, 1)
+    target_s = 12.0
+    per_core = max(1, int(target_s / (2 * max(t1, 1e-4))))
+    batch = min(per_core * cores, 4096)
+    buf = np.tile(one * np.float32(1e-30), batch)
+    t = fwd.time_batch(buf, batch, 1, cores) + inv.time_batch(buf, batch, 1, cores)
+    flops = 2 * batch * 5.0 * n * math.log2(n)
+    log(f"cpu_baseline: {batch} transforms fwd+inv on {cores} threads in {t:.2f}s")
+    return {"value": flops / t / 1e9, "unit": "GFLOP/s", "cores": cores, "kind": "port",
+            "sample": f"N=2^{int(math.log2(n))} Complex<f32>, {batch} transforms forward+inverse, {cores} caller threads sharing one plan "
+                      f"(scalar-path restatement compiled -O2 -ffp-contract=off, not the RustFFT binary)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2n", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1024, help="transforms per GPU")
+    ap.add_argument("--chunk", type=int, default=-1, help="transforms per workspace chunk (-1 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import rustfft_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+
+    def log(msg):
+        if rank == 0:
+            print(msg, file=sys.stderr, flush=True)
+
+    n, batch = 1 << args.log2n, args.batch
+    planner = rustfft_amd.FftPlanner(np.complex64, device=local_rank)
+    fwd, inv = planner.plan_fft_forward(n), planner.plan_fft_inverse(n)
+    if args.chunk >= 0:
+        fwd.set_chunk_batch(args.chunk)
+        inv.set_chunk_batch(args.chunk)
+    log(f"plan: {fwd.describe()}")
+
+    # synthetic data, re/im ~ U[0,10) (tests/accuracy.rs:84-95), pre-scaled by 2^-100 so that the
+    # unnormalised forward+inverse pair (x -> N x per step) stays finite in f32 for <= 10 steps
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x52555354 + rank)
+    data = torch.empty(batch * n, dtype=torch.complex64, device="cuda")
+    torch.view_as_real(data).uniform_(0.0, 10.0, generator=g)
+    scale0 = 2.0 ** -100
+    data.mul_(scale0)
+    renorm_every = max(1, 224 // args.log2n)  # steps before magnitudes approach 2^128 (11 at N = 2^20)
+
+    def step(i):
+        fwd.process(data)
+        inv.process(data)
+        if (i + 1) % renorm_every == 0:  # only reached when warmup+steps exceeds the finite range
+            data.mul_(float(n) ** (-renorm_every))
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    finite = bool(torch.isfinite(torch.view_as_real(data[: 1 << 16])).all().item())
+
+    flops_per_step = world * 2 * batch * 5.0 * n * math.log2(n)
+    value = flops_per_step * args.steps / elapsed / 1e9
+
+    out = {
+        "metric": "GFLOP/s (5*N*log2N), batched Complex<f32> FFT", "value": value, "unit": "GFLOP/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"N=2^{args.log2n} Complex<f32>, batch={batch} per GPU, forward+inverse per step, in place, HBM-resident",
+                   "plan": fwd.describe(), "finite": finite},
+    }
+    if rank == 0:
+        # per-kernel durations with HIP events on the launch stream, same buffers, same step count
+        torch.cuda.synchronize()
+        ms_f = fwd.profile_kernels(data, reps=args.steps)
+        ms_i = inv.profile_kernels(data, reps=args.steps)
+        names = fwd.kernel_names()
+        alg_bytes = batch * 2 * n * 8  # one compulsory read + one write of the data per launch
+        per_kernel = []
+        for k, nm in enumerate(names):
+            ms = 0.5 * (ms_f[k] + ms_i[k])
+            per_kernel.append({"kernel": nm, "ms": ms, "GBps": alg_bytes / (ms * 1e-3) / 1e9})
+        dom = max(per_kernel, key=lambda r: r["ms"])
+        out["roofline"] = {"bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": None, "kernel": dom["kernel"],
+                           "kernels": per_kernel,
+                           "transform_algorithmic_frac": (batch * 2 * n * 8) / (sum(r["ms"] for r in per_kernel) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(n, log)
+            except Exception as e:  # the baseline is a reported side number; never fail the bench on it
+                out["cpu_baseline"] = {"value": None, "unit": "GFLOP/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

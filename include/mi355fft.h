@@ -1,0 +1,120 @@
+/* mi355fft — C ABI of the MI355X (gfx950) engine behind RustFFT's `Fft<T>::process()` hot path.
+ *
+ * This header is the drop-in boundary.  RustFFT has no FFI today; the seam is the `Fft<T>` trait object
+ * that `FftPlanner::plan_fft` returns (reference: src/lib.rs:184-278, src/plan.rs:72-126).  Each entry
+ * point below names the reference interface it replaces; INTEGRATION.md shows the Rust `extern "C"` block
+ * and the `impl Fft<T> for HipFft<T>` a maintainer would add next to src/avx/avx_planner.rs.
+ *
+ * Conventions (identical to the reference, src/lib.rs:81-89):
+ *   - data is interleaved Complex<T> = {re, im} of float (precision 32) or double (precision 64);
+ *   - a call transforms `batch = n_elems / len` independent sequences stored back to back;
+ *   - natural order in and out, unnormalised in both directions;
+ *   - direction 0 = FftDirection::Forward (exp(-2 pi i jk/N)), 1 = FftDirection::Inverse.
+ * All functions return MI355FFT_OK (0) or a negative/positive status; mi355fft_strerror() maps it to
+ * text, and for the validation failures the text is the reference's panic message
+ * (src/common.rs:13-104) so the Rust shim can `panic!` with it verbatim.
+ * A plan is immutable after creation: any number of host threads may call process_* on one plan
+ * concurrently (reference contract: `Fft: Send + Sync`, examples/concurrency.rs:9-30).
+ * There is NO CPU fallback inside this library: without a gfx950 device every call fails with
+ * MI355FFT_ERR_NO_DEVICE.
+ */
+#ifndef MI355FFT_H
+#define MI355FFT_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mi355fft_plan mi355fft_plan;
+
+enum {
+    MI355FFT_OK = 0,
+    MI355FFT_ERR_NO_DEVICE = 1,        /* no gfx950 GPU / HIP runtime failure at init            */
+    MI355FFT_ERR_BUFFER_TOO_SMALL = 2, /* common.rs:19-24   "Provided FFT buffer was too small"  */
+    MI355FFT_ERR_NOT_MULTIPLE = 3,     /* common.rs:25-31   "must be a multiple of FFT length"   */
+    MI355FFT_ERR_SCRATCH_TOO_SMALL = 4,/* common.rs:32-37   "Not enough scratch space"           */
+    MI355FFT_ERR_LENGTH_MISMATCH = 5,  /* common.rs:51      input.len() != output.len()          */
+    MI355FFT_ERR_UNSUPPORTED = 6,      /* length/precision this build cannot plan on the GPU     */
+    MI355FFT_ERR_INVALID_ARG = 7,
+    MI355FFT_ERR_HIP = 8,              /* HIP runtime error, see mi355fft_last_error()           */
+    MI355FFT_ERR_OUT_OF_MEMORY = 9
+};
+
+enum { MI355FFT_FORWARD = 0, MI355FFT_INVERSE = 1 };
+enum { MI355FFT_SCRATCH_INPLACE = 0, MI355FFT_SCRATCH_OUTOFPLACE = 1, MI355FFT_SCRATCH_IMMUTABLE = 2 };
+
+/* ---- device probe -----------------------------------------------------------------------------------
+ * Replaces the ISA probe of a SIMD planner (`FftPlannerAvx::new() -> Result<Self, ()>`,
+ * src/avx/avx_planner.rs:113-164; chooser chain src/plan.rs:72-94): `FftPlannerHip::new()` returns
+ * Err(()) when mi355fft_device_count() == 0 or mi355fft_init() fails, and FftPlanner falls through to
+ * the next back-end exactly as it does for a missing ISA. */
+int mi355fft_device_count(void);
+int mi355fft_init(int device);
+
+/* ---- planning ---------------------------------------------------------------------------------------
+ * Replaces `FftPlanner::plan_fft(len, direction) -> Arc<dyn Fft<T>>` (src/plan.rs:101-111, 289-295) for
+ * the HIP back-end: builds the device twiddle/index tables and picks the kernel sequence.
+ * precision: 32 (Complex<f32>) or 64 (Complex<f64>).  The plan is bound to the device current at
+ * creation.  `Drop for HipFft<T>` calls mi355fft_plan_destroy. */
+int mi355fft_plan_create(size_t len, int direction, int precision, mi355fft_plan** out_plan);
+int mi355fft_plan_destroy(mi355fft_plan* plan);
+
+/* `Length::len`, `Direction::fft_direction` (src/lib.rs:140-143, 174-177) */
+size_t mi355fft_plan_len(const mi355fft_plan* plan);
+int mi355fft_plan_direction(const mi355fft_plan* plan);
+int mi355fft_plan_precision(const mi355fft_plan* plan);
+/* `Fft::get_inplace_scratch_len / get_outofplace_scratch_len / get_immutable_scratch_len`
+ * (src/lib.rs:262-277).  Host-side scratch is 0 for every mode: the workspace lives in HBM and is owned
+ * by the plan (the reference allows these numbers to change between versions, src/lib.rs:259-261). */
+size_t mi355fft_scratch_len(const mi355fft_plan* plan, int mode);
+/* Human-readable kernel plan, e.g. "k2first<1024..>xF16 -> k2later<1024..>xF16" (diagnostics only). */
+int mi355fft_plan_describe(const mi355fft_plan* plan, char* buf, size_t cap);
+
+/* ---- host-slice entry points: the literal drop-ins for the three trait methods ------------------------
+ * Replace `Fft::process_with_scratch` (src/lib.rs:211), `process_outofplace_with_scratch` (:231, may
+ * clobber `input`) and `process_immutable_with_scratch` (:250).  Pointers are host memory; n_* are
+ * element (Complex<T>) counts; scratch may be NULL when scratch_elems == 0.  Validation order and
+ * outcomes follow src/fft_helper.rs:9-150 + src/array_utils.rs:151-327: len == 0 is a no-op; an empty
+ * buffer is accepted; otherwise scratch-too-small is reported before any work, and a trailing partial
+ * chunk is reported AFTER all complete chunks have been transformed.  Each call stages H2D, runs the
+ * kernels and copies back before returning. */
+int mi355fft_process_inplace_host(const mi355fft_plan* plan, void* buffer, size_t n_elems, void* scratch,
+                                  size_t scratch_elems);
+int mi355fft_process_outofplace_host(const mi355fft_plan* plan, void* input, size_t n_in, void* output, size_t n_out,
+                                     void* scratch, size_t scratch_elems);
+int mi355fft_process_immutable_host(const mi355fft_plan* plan, const void* input, size_t n_in, void* output,
+                                    size_t n_out, void* scratch, size_t scratch_elems);
+
+/* ---- device-resident entry points: the measured path ---------------------------------------------------
+ * Same three modes on HBM-resident buffers (16-byte aligned device pointers), asynchronous on `stream`
+ * (a hipStream_t passed as void*; NULL = the default stream).  `batch` = number of length-len sequences.
+ * The large-N passes use a plan-owned HBM workspace of batch*len elements for in-place calls
+ * (allocated on first use, grown on demand, protected for concurrent callers). */
+int mi355fft_process_inplace_dev(const mi355fft_plan* plan, void* buffer, size_t batch, void* stream);
+int mi355fft_process_outofplace_dev(const mi355fft_plan* plan, void* input, void* output, size_t batch, void* stream);
+int mi355fft_process_immutable_dev(const mi355fft_plan* plan, const void* input, void* output, size_t batch,
+                                   void* stream);
+
+/* ---- measurement hooks (used by bench.py; not part of the reference surface) -----------------------------
+ * Number of kernel launches one in-place transform of this plan issues, and their names. */
+int mi355fft_plan_num_kernels(const mi355fft_plan* plan);
+const char* mi355fft_plan_kernel_name(const mi355fft_plan* plan, int index);
+/* Runs the in-place transform `reps` times on `stream` with every kernel launch bracketed by HIP events
+ * recorded on that stream; ms_per_kernel[i] receives the mean duration of kernel i in milliseconds. */
+int mi355fft_profile_inplace_dev(const mi355fft_plan* plan, void* buffer, size_t batch, void* stream, int reps,
+                                 float* ms_per_kernel, int n_kernels);
+/* Tunables (0 = library default): transforms per workspace chunk of the multi-pass path. */
+int mi355fft_plan_set_chunk_batch(mi355fft_plan* plan, size_t chunk_batch);
+
+const char* mi355fft_strerror(int status);
+/* Detailed message of the calling thread's most recent failure (the reference's panic text for the
+ * validation errors, the HIP error string for MI355FFT_ERR_HIP). */
+const char* mi355fft_last_error(void);
+const char* mi355fft_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355FFT_H */

@@ -1,0 +1,8 @@
+"""rustfft_amd — MI355X-native engine behind RustFFT's `Fft<T>::process()` hot path.
+
+Host-side mirror of the reference's planner/trait surface (src/plan.rs:72-126, src/lib.rs:140-278) over the
+C ABI of include/mi355fft.h.  The compute path is the HIP library only (no CPU fallback).
+"""
+from .planner import Fft, FftDirection, FftPanic, FftPlanner, FftPlannerHip, device_count  # noqa: F401
+
+__all__ = ["Fft", "FftDirection", "FftPanic", "FftPlanner", "FftPlannerHip", "device_count"]

@@ -1,0 +1,69 @@
+"""ctypes loader for rustfft_amd/lib/libmi355fft.so (the C ABI in include/mi355fft.h).
+
+There is deliberately no fallback: if the shared library is missing it must be built
+(`python -c "import __graft_entry__ as g; g.build()"` or `make -C rustfft_amd/csrc`), and if no gfx950 GPU
+is visible every planning call fails with MI355FFT_ERR_NO_DEVICE.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmi355fft.so")
+
+EXPORTS = [
+    "mi355fft_device_count", "mi355fft_init", "mi355fft_plan_create", "mi355fft_plan_destroy", "mi355fft_plan_len",
+    "mi355fft_plan_direction", "mi355fft_plan_precision", "mi355fft_scratch_len", "mi355fft_plan_describe",
+    "mi355fft_process_inplace_host", "mi355fft_process_outofplace_host", "mi355fft_process_immutable_host",
+    "mi355fft_process_inplace_dev", "mi355fft_process_outofplace_dev", "mi355fft_process_immutable_dev",
+    "mi355fft_plan_num_kernels", "mi355fft_plan_kernel_name", "mi355fft_profile_inplace_dev",
+    "mi355fft_plan_set_chunk_batch", "mi355fft_strerror", "mi355fft_last_error", "mi355fft_version",
+]
+
+
+def bind(lib):
+    """Attach argtypes/restypes for every symbol include/mi355fft.h declares."""
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    lib.mi355fft_device_count.restype = ci
+    lib.mi355fft_init.argtypes = [ci]
+    lib.mi355fft_plan_create.argtypes = [sz, ci, ci, ctypes.POINTER(vp)]
+    lib.mi355fft_plan_destroy.argtypes = [vp]
+    lib.mi355fft_plan_len.restype = sz
+    lib.mi355fft_plan_len.argtypes = [vp]
+    lib.mi355fft_plan_direction.argtypes = [vp]
+    lib.mi355fft_plan_precision.argtypes = [vp]
+    lib.mi355fft_scratch_len.restype = sz
+    lib.mi355fft_scratch_len.argtypes = [vp, ci]
+    lib.mi355fft_plan_describe.argtypes = [vp, ctypes.c_char_p, sz]
+    lib.mi355fft_process_inplace_host.argtypes = [vp, vp, sz, vp, sz]
+    lib.mi355fft_process_outofplace_host.argtypes = [vp, vp, sz, vp, sz, vp, sz]
+    lib.mi355fft_process_immutable_host.argtypes = [vp, vp, sz, vp, sz, vp, sz]
+    lib.mi355fft_process_inplace_dev.argtypes = [vp, vp, sz, vp]
+    lib.mi355fft_process_outofplace_dev.argtypes = [vp, vp, vp, sz, vp]
+    lib.mi355fft_process_immutable_dev.argtypes = [vp, vp, vp, sz, vp]
+    lib.mi355fft_plan_num_kernels.argtypes = [vp]
+    lib.mi355fft_plan_kernel_name.restype = ctypes.c_char_p
+    lib.mi355fft_plan_kernel_name.argtypes = [vp, ci]
+    lib.mi355fft_profile_inplace_dev.argtypes = [vp, vp, sz, vp, ci, ctypes.POINTER(ctypes.c_float), ci]
+    lib.mi355fft_plan_set_chunk_batch.argtypes = [vp, sz]
+    lib.mi355fft_strerror.restype = ctypes.c_char_p
+    lib.mi355fft_strerror.argtypes = [ci]
+    lib.mi355fft_last_error.restype = ctypes.c_char_p
+    lib.mi355fft_version.restype = ctypes.c_char_p
+    return lib
+
+
+_lib = None
+
+
+def load(path=None):
+    """Load the HIP library.  `path` exists only so tests can inject tests/emu's kernel-body emulator."""
+    global _lib
+    if path is not None:
+        return bind(ctypes.CDLL(path))
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+                "rustfft_amd has no CPU fallback.")
+        _lib = bind(ctypes.CDLL(LIB_PATH))
+    return _lib

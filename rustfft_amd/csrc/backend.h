@@ -1,0 +1,24 @@
+// Thin device-runtime seam used by the host planner: HIP in the product build
+// (backend_hip.hip), plain host memory in the kernel-body emulator build (tests/emu).
+#pragma once
+#include <cstddef>
+#include <string>
+
+namespace mi355 {
+namespace backend {
+int device_count();
+int init(int device);              // 0 on success
+void* dmalloc(size_t bytes);       // nullptr on failure
+void dfree(void* p);
+int h2d(void* d, const void* h, size_t bytes, void* stream);
+int d2h(void* h, const void* d, size_t bytes, void* stream);
+int d2d(void* dst, const void* src, size_t bytes, void* stream);
+int sync(void* stream);
+int check_launch();                // last launch error -> 0 / nonzero
+std::string last_error();
+void* event_create();
+void event_destroy(void* e);
+void event_record(void* e, void* stream);
+float event_elapsed_ms(void* a, void* b);  // synchronises on b
+}  // namespace backend
+}  // namespace mi355

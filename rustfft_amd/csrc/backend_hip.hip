@@ -1,0 +1,61 @@
+// HIP implementation of the backend seam (product build).
+#include <hip/hip_runtime.h>
+
+#include "backend.h"
+
+namespace mi355 {
+namespace backend {
+static thread_local std::string g_err;
+static int fail(hipError_t e) {
+    if (e == hipSuccess) return 0;
+    g_err = hipGetErrorString(e);
+    return (int)e;
+}
+int device_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int gfx950 = 0;
+    for (int i = 0; i < n; ++i) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && std::string(p.gcnArchName).rfind("gfx950", 0) == 0) ++gfx950;
+    }
+    return gfx950;
+}
+int init(int device) {
+    hipDeviceProp_t p;
+    if (int rc = fail(hipGetDeviceProperties(&p, device))) return rc;
+    if (std::string(p.gcnArchName).rfind("gfx950", 0) != 0) {
+        g_err = std::string("device is not gfx950: ") + p.gcnArchName;
+        return -1;
+    }
+    return fail(hipSetDevice(device));
+}
+void* dmalloc(size_t bytes) {
+    void* p = nullptr;
+    if (fail(hipMalloc(&p, bytes ? bytes : 16))) return nullptr;
+    return p;
+}
+void dfree(void* p) {
+    if (p) (void)hipFree(p);
+}
+int h2d(void* d, const void* h, size_t bytes, void* s) { return fail(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, (hipStream_t)s)); }
+int d2h(void* h, const void* d, size_t bytes, void* s) { return fail(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)s)); }
+int d2d(void* dst, const void* src, size_t bytes, void* s) { return fail(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s)); }
+int sync(void* s) { return fail(hipStreamSynchronize((hipStream_t)s)); }
+int check_launch() { return fail(hipGetLastError()); }
+std::string last_error() { return g_err; }
+void* event_create() {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return (void*)e;
+}
+void event_destroy(void* e) { (void)hipEventDestroy((hipEvent_t)e); }
+void event_record(void* e, void* s) { (void)hipEventRecord((hipEvent_t)e, (hipStream_t)s); }
+float event_elapsed_ms(void* a, void* b) {
+    float ms = 0;
+    (void)hipEventSynchronize((hipEvent_t)b);
+    (void)hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b);
+    return ms;
+}
+}  // namespace backend
+}  // namespace mi355

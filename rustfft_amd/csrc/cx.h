@@ -1,0 +1,88 @@
+// Complex arithmetic + compile-time twiddle constants shared by the gfx950 kernels and the
+// host-side kernel-body emulator (tests/emu).  Layout matches num_complex::Complex<T>
+// (#[repr(C)] {re, im}), i.e. what RustFFT's Fft<T>::process() receives (src/lib.rs:195).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MI_HD __host__ __device__ __forceinline__
+#define MI_RESTRICT __restrict__
+#else
+#define MI_HD inline __attribute__((always_inline))
+#define MI_RESTRICT __restrict__
+#endif
+
+namespace mi355 {
+
+template <class T> struct cx {
+    T re, im;
+};
+template <class T> MI_HD cx<T> operator+(cx<T> a, cx<T> b) { return {a.re + b.re, a.im + b.im}; }
+template <class T> MI_HD cx<T> operator-(cx<T> a, cx<T> b) { return {a.re - b.re, a.im - b.im}; }
+template <class T> MI_HD cx<T> operator*(cx<T> a, cx<T> b) {
+    return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
+}
+template <class T> MI_HD cx<T> operator*(cx<T> a, T s) { return {a.re * s, a.im * s}; }
+template <class T> MI_HD cx<T> cconj(cx<T> a) { return {a.re, -a.im}; }
+// multiply by -i (forward quarter turn; the reference's rotate_90, src/twiddles.rs:59-70)
+template <class T> MI_HD cx<T> mul_neg_i(cx<T> a) { return {a.im, -a.re}; }
+template <class T> MI_HD cx<T> mul_pos_i(cx<T> a) { return {-a.im, a.re}; }
+
+// ---- compile-time exp(-2*pi*i*m/n) -----------------------------------------------------------
+// Exact octant reduction on the integers (m, n), then a Taylor series on [0, pi/4]; evaluated by
+// the compiler, so radix-internal constants cost no table traffic.  Accuracy ~1e-16.
+namespace detail {
+constexpr double kPi = 3.14159265358979323846264338327950288;
+constexpr double sin_small(double x) {
+    double x2 = x * x, term = x, sum = x;
+    for (int i = 1; i <= 14; ++i) {
+        term *= -x2 / double((2 * i) * (2 * i + 1));
+        sum += term;
+    }
+    return sum;
+}
+constexpr double cos_small(double x) {
+    double x2 = x * x, term = 1.0, sum = 1.0;
+    for (int i = 1; i <= 14; ++i) {
+        term *= -x2 / double((2 * i - 1) * (2 * i));
+        sum += term;
+    }
+    return sum;
+}
+struct cd {
+    double re, im;
+};
+// cos/sin of 2*pi*m/n for 0 <= m < n
+constexpr cd unit_root(long long m, long long n) {
+    m %= n;
+    if (m < 0) m += n;
+    // quadrant q in 0..3 and remainder r: 4m = q*n + r, angle = q*pi/2 + (pi/2)*(r/n)
+    long long q = (4 * m) / n, r = (4 * m) % n;
+    double c = 0, s = 0;
+    if (2 * r <= n) {  // phi <= pi/4
+        double phi = (kPi / 2) * double(r) / double(n);
+        c = cos_small(phi);
+        s = sin_small(phi);
+    } else {  // use the complement so the series argument stays <= pi/4
+        double psi = (kPi / 2) * double(n - r) / double(n);
+        c = sin_small(psi);
+        s = cos_small(psi);
+    }
+    switch (q) {
+        case 0: return {c, s};
+        case 1: return {-s, c};
+        case 2: return {-c, -s};
+        default: return {s, -c};
+    }
+}
+}  // namespace detail
+
+// forward twiddle exp(-2*pi*i*m/n) as a compile-time constant of type cx<T>
+template <class T, int M, int N> MI_HD constexpr cx<T> ctw() {
+    constexpr detail::cd u = detail::unit_root(M, N);
+    return cx<T>{(T)u.re, (T)(-u.im)};
+}
+
+}  // namespace mi355

@@ -1,0 +1,254 @@
+// Workgroup-level Stockham FFT engine for gfx950 (wave64, LDS exchange), shared with the host
+// emulator of the kernel bodies (tests/emu) through the `X` executor parameter.
+//
+// One workgroup transforms F independent length-N sequences.  TPF threads cooperate on each
+// sequence; a thread keeps the inputs of its radix-R butterflies in VGPRs, and the only data
+// movement between the NP sub-passes is one transposition through LDS.  Sub-pass p (radix R_p,
+// stride s_p = R_0..R_{p-1}, nb_p = N/R_p butterflies), butterfly b:
+//     in_k  = x[b + k*nb_p]                       * w_{s_p R_p}^{(b mod s_p) k}
+//     out_k -> y[(b div s_p) s_p R_p + (b mod s_p) + k s_p]
+// (autosort form: natural order in, natural order out, no digit reversal pass — this is what
+// replaces the reference's bitreversed_transpose / factor_transpose + butterfly_N column loops,
+// src/array_utils.rs:372-509 and src/algorithm/radixn.rs:338-490.)
+//
+// The first sub-pass reads straight from the caller's `src` functor (global memory, or LDS for the
+// Rader/Bluestein bodies) and the last one writes straight to `dst`, so an NP-pass transform costs
+// NP-1 LDS round trips.  Thread -> (sequence f, slot u) mappings:
+//   MAP_EF  element-fastest: lanes walk along one sequence  (contiguous batched transforms)
+//   MAP_FF  fft-fastest:     lanes walk across the F sequences (column tiles of the large-N passes)
+// SPLIT = true exchanges the real and imaginary planes one after the other through a half-size
+// LDS buffer (4 barriers instead of 2 per exchange) so that R*F = 16K-element tiles fit twice per CU.
+#pragma once
+#include "butterflies.h"
+
+namespace mi355 {
+
+enum Map { MAP_EF = 0, MAP_FF = 1 };
+
+template <int N_, int TPF_, int... Rs> struct Sched {
+    static constexpr int N = N_, TPF = TPF_, NP = (int)sizeof...(Rs);
+    static constexpr int R[sizeof...(Rs)] = {Rs...};
+    static constexpr int radix(int p) { return R[p]; }
+    static constexpr int stride(int p) {
+        int s = 1;
+        for (int q = 0; q < p; ++q) s *= R[q];
+        return s;
+    }
+    static constexpr int nb(int p) { return N / R[p]; }
+    static constexpr int bpt(int p) { return (nb(p) + TPF - 1) / TPF; }
+    static constexpr int emax() {
+        int e = 0;
+        for (int p = 0; p < NP; ++p) e = (R[p] * bpt(p) > e) ? R[p] * bpt(p) : e;
+        return e;
+    }
+    // sub-pass twiddle table: pass p >= 1 owns (R_p - 1) * s_p entries, laid out [k-1][b mod s_p]
+    static constexpr int tw_offset(int p) {
+        int o = 0;
+        for (int q = 1; q < p; ++q) o += (R[q] - 1) * stride(q);
+        return o;
+    }
+    static constexpr int tw_total() { return tw_offset(NP); }
+    // LDS padding: one extra slot every PADDIV elements makes the stride-R_0 scatter of the first
+    // exchange conflict-free (bank math: MI355X_MICROARCH.md §LDS)
+    static constexpr int paddiv() { return (NP > 1 && R[0] % 2 == 0) ? R[0] : 0; }
+    static constexpr int phys(int i) {
+        constexpr int d = paddiv();
+        if constexpr (d != 0)
+            return i + i / d;
+        else
+            return i;
+    }
+    static constexpr int pitch() { return (phys(N - 1) + 1) | 1; }  // odd pitch: MAP_FF lanes hit distinct banks
+    static constexpr bool valid() {
+        int prod = 1;
+        for (int p = 0; p < NP; ++p) prod *= R[p];
+        return prod == N;
+    }
+};
+
+template <class S> MI_HD int lds_phys(int i) {
+    if constexpr (S::paddiv() != 0)
+        return i + i / S::paddiv();
+    else
+        return i;
+}
+
+template <Map M, int F, int TPF> MI_HD void map_tid(int tid, int& f, int& u) {
+    if constexpr (M == MAP_EF) {
+        u = tid % TPF;
+        f = tid / TPF;
+    } else {
+        f = tid % F;
+        u = tid / F;
+    }
+}
+
+// ---- one sub-pass worth of arithmetic on the registers ------------------------------------------
+template <class T, class S, int P> MI_HD void compute_pass(cx<T>* v, int u, const cx<T>* MI_RESTRICT tw) {
+    constexpr int R = S::R[P], NB = S::nb(P), ST = S::stride(P), BPT = S::bpt(P);
+    static_for<0, BPT>([&](auto M_) {
+        constexpr int m = M_;
+        const int b = u + m * S::TPF;
+        if ((m + 1) * S::TPF <= NB || b < NB) {
+            if constexpr (ST > 1) {
+                const cx<T>* t = tw + S::tw_offset(P) + (b % ST);
+                static_for<1, R>([&](auto K_) {
+                    constexpr int k = K_;
+                    v[m * R + k] = v[m * R + k] * t[(k - 1) * ST];
+                });
+            }
+            butterfly<R>(v + m * R);
+        }
+    });
+}
+
+// ---- LDS exchange halves ---------------------------------------------------------------------------
+// PART: 0 = whole complex value (E = cx<T>), 1 = real plane, 2 = imaginary plane (E = T)
+template <class T, class S, int P, int PART, class E> MI_HD void lds_scatter(const cx<T>* v, int u, E* ldsf) {
+    constexpr int R = S::R[P], NB = S::nb(P), ST = S::stride(P), BPT = S::bpt(P);
+    static_for<0, BPT>([&](auto M_) {
+        constexpr int m = M_;
+        const int b = u + m * S::TPF;
+        if ((m + 1) * S::TPF <= NB || b < NB) {
+            const int base = (b / ST) * (ST * R) + (b % ST);
+            static_for<0, R>([&](auto K_) {
+                constexpr int k = K_;
+                const int o = lds_phys<S>(base + k * ST);
+                if constexpr (PART == 0)
+                    ldsf[o] = v[m * R + k];
+                else if constexpr (PART == 1)
+                    ldsf[o] = v[m * R + k].re;
+                else
+                    ldsf[o] = v[m * R + k].im;
+            });
+        }
+    });
+}
+template <class T, class S, int P, int PART, class E> MI_HD void lds_gather(cx<T>* v, int u, const E* ldsf) {
+    constexpr int R = S::R[P], NB = S::nb(P), BPT = S::bpt(P);
+    static_for<0, BPT>([&](auto M_) {
+        constexpr int m = M_;
+        const int b = u + m * S::TPF;
+        if ((m + 1) * S::TPF <= NB || b < NB) {
+            static_for<0, R>([&](auto K_) {
+                constexpr int k = K_;
+                const int o = lds_phys<S>(b + k * NB);
+                if constexpr (PART == 0)
+                    v[m * R + k] = ldsf[o];
+                else if constexpr (PART == 1)
+                    v[m * R + k].re = ldsf[o];
+                else
+                    v[m * R + k].im = ldsf[o];
+            });
+        }
+    });
+}
+
+template <class S, int P, Map MIN, Map MOUT> constexpr Map pass_map() {
+    return P == 0 ? MIN : (P == S::NP - 1 ? MOUT : MAP_EF);
+}
+
+// ---- the workgroup transform -------------------------------------------------------------------------
+// X: executor. X::for_threads(fn(tid, cx<T>* v)) runs fn for every thread of the workgroup with that
+//    thread's private register array; X::barrier() is the workgroup barrier.
+// src(f, i) -> cx<T>: input element i of sequence f;   dst(f, i, value): output element i.
+template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, int P, class X, class SRC, class DST>
+MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& src, DST& dst) {
+    constexpr int R = S::R[P], NB = S::nb(P), ST = S::stride(P), BPT = S::bpt(P);
+    constexpr Map MP = pass_map<S, P, MIN, MOUT>();
+    constexpr bool LAST = (P == S::NP - 1);
+    // arithmetic of pass P, then either the final store or the scatter half of the exchange
+    ex.for_threads([&](int tid, cx<T>* v) {
+        int f, u;
+        map_tid<MP, F, S::TPF>(tid, f, u);
+        compute_pass<T, S, P>(v, u, tw);
+        if constexpr (LAST) {
+            static_for<0, BPT>([&](auto M_) {
+                constexpr int m = M_;
+                const int b = u + m * S::TPF;
+                if ((m + 1) * S::TPF <= NB || b < NB) {
+                    const int base = (b / ST) * (ST * R) + (b % ST);
+                    static_for<0, R>([&](auto K_) {
+                        constexpr int k = K_;
+                        dst(f, base + k * ST, v[m * R + k]);
+                    });
+                }
+            });
+        } else if constexpr (!SPLIT) {
+            lds_scatter<T, S, P, 0>(v, u, (cx<T>*)lds_raw + f * S::pitch());
+        } else {
+            lds_scatter<T, S, P, 1>(v, u, (T*)lds_raw + f * S::pitch());
+        }
+    });
+    if constexpr (!LAST) {
+        constexpr Map MQ = pass_map<S, P + 1, MIN, MOUT>();
+        ex.barrier();
+        if constexpr (!SPLIT) {
+            ex.for_threads([&](int tid, cx<T>* v) {
+                int f, u;
+                map_tid<MQ, F, S::TPF>(tid, f, u);
+                lds_gather<T, S, P + 1, 0>(v, u, (const cx<T>*)lds_raw + f * S::pitch());
+            });
+            ex.barrier();
+        } else {
+            // real plane out, imaginary plane in flight: the new real parts land in a side array so the
+            // old imaginary parts (still needed for the second scatter) are not overwritten
+            ex.for_threads([&](int tid, cx<T>* v) {
+                int f, u;
+                map_tid<MQ, F, S::TPF>(tid, f, u);
+                cx<T>* side = v + S::emax();
+                lds_gather<T, S, P + 1, 1>(side, u, (const T*)lds_raw + f * S::pitch());
+            });
+            ex.barrier();
+            ex.for_threads([&](int tid, cx<T>* v) {
+                int f, u;
+                map_tid<MP, F, S::TPF>(tid, f, u);
+                lds_scatter<T, S, P, 2>(v, u, (T*)lds_raw + f * S::pitch());
+            });
+            ex.barrier();
+            ex.for_threads([&](int tid, cx<T>* v) {
+                int f, u;
+                map_tid<MQ, F, S::TPF>(tid, f, u);
+                cx<T>* side = v + S::emax();
+                lds_gather<T, S, P + 1, 2>(side, u, (const T*)lds_raw + f * S::pitch());
+                static_for<0, S::emax()>([&](auto I_) {
+                    constexpr int i = I_;
+                    v[i] = side[i];
+                });
+            });
+            ex.barrier();
+        }
+        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, P + 1>(ex, lds_raw, tw, src, dst);
+    }
+}
+
+// register array length an executor must provide per thread
+template <class S, bool SPLIT> constexpr int regs_needed() { return SPLIT ? 2 * S::emax() : S::emax(); }
+// LDS bytes one workgroup needs
+template <class T, class S, int F, bool SPLIT> constexpr size_t lds_bytes() {
+    return (S::NP > 1) ? (size_t)F * S::pitch() * (SPLIT ? sizeof(T) : sizeof(cx<T>)) : 0;
+}
+
+template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, class X, class SRC, class DST>
+MI_HD void wg_fft(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC src, DST dst) {
+    static_assert(S::valid(), "radices must multiply to N");
+    constexpr int R0 = S::R[0], NB0 = S::nb(0), BPT0 = S::bpt(0);
+    // inputs of sub-pass 0 straight from the source
+    ex.for_threads([&](int tid, cx<T>* v) {
+        int f, u;
+        map_tid<MIN, F, S::TPF>(tid, f, u);
+        static_for<0, BPT0>([&](auto M_) {
+            constexpr int m = M_;
+            const int b = u + m * S::TPF;
+            if ((m + 1) * S::TPF <= NB0 || b < NB0) {
+                static_for<0, R0>([&](auto K_) {
+                    constexpr int k = K_;
+                    v[m * R0 + k] = src(f, b + k * NB0);
+                });
+            }
+        });
+    });
+    wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, 0>(ex, lds_raw, tw, src, dst);
+}
+
+}  // namespace mi355

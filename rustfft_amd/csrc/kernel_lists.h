@@ -1,0 +1,21 @@
+// The compiled kernel instantiations.  Sched<N, TPF, radices...>: TPF threads per sequence; a thread
+// holds at most 16 (32 for the 1024-row tile) complex values in VGPRs.
+// K1 lists: batched contiguous transforms (one launch per Fft::process call).
+// K2 lists: column-tile passes of the large-N decomposition, tile width F chosen so that
+//           F * sizeof(Complex<T>) >= 128 contiguous bytes per row and two workgroups fit a CU's LDS.
+#pragma once
+
+#define MI_K1_LIST(T, PREC)                           \
+    MI_K1(T, PREC, 256, false, 2, 1, 2);              \
+    MI_K1(T, PREC, 256, false, 4, 1, 4);              \
+    MI_K1(T, PREC, 128, false, 8, 1, 8);              \
+    MI_K1(T, PREC, 64, false, 16, 4, 4, 4);           \
+    MI_K1(T, PREC, 64, false, 32, 4, 8, 4);           \
+    MI_K1(T, PREC, 32, false, 64, 8, 8, 8);           \
+    MI_K1(T, PREC, 32, false, 128, 8, 16, 8);         \
+    MI_K1(T, PREC, 16, false, 256, 16, 16, 16);       \
+    MI_K1(T, PREC, 8, false, 512, 32, 16, 8, 4);      \
+    MI_K1(T, PREC, 4, false, 1024, 64, 16, 16, 4);    \
+    MI_K1(T, PREC, 2, false, 2048, 128, 16, 16, 8);   \
+    MI_K1(T, PREC, 1, false, 4096, 256, 16, 16, 16)
+

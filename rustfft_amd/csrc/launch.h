@@ -1,0 +1,137 @@
+// Executors + launch thunks.  HIP build: DevExec + __global__ wrappers.  Emulator build
+// (MI355_EMU, tests/emu only): HostExec runs every thread of a workgroup phase by phase on the CPU,
+// which checks all index arithmetic of the kernel bodies without a GPU.
+#pragma once
+#include <vector>
+
+#include "kernels.h"
+#include "registry.h"
+
+namespace mi355 {
+
+#if !defined(MI355_EMU)
+// -------------------------------------------------------------------------------- gfx950
+template <class T, int NREG> struct DevExec {
+    cx<T> v[NREG];
+    template <class Fn> __device__ __forceinline__ void for_threads(Fn&& fn) { fn((int)threadIdx.x, v); }
+    __device__ __forceinline__ void barrier() { __syncthreads(); }
+};
+
+template <class T, class S, int F, bool SPLIT>
+__global__ __launch_bounds__(F* S::TPF) void k1_kernel(K1Params<T> p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevExec<T, regs_needed<S, SPLIT>()> ex;
+    k1_body<T, S, F, SPLIT>(ex, p, (long long)blockIdx.x, smem);
+}
+template <class T, class S, int F, bool FIRST, bool SPLIT>
+__global__ __launch_bounds__(F* S::TPF) void k2_kernel(K2Params<T> p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevExec<T, regs_needed<S, SPLIT>()> ex;
+    k2_body<T, S, F, FIRST, SPLIT>(ex, p, (long long)blockIdx.x, smem);
+}
+
+template <class T, class S, int F, bool SPLIT> KernelEntry make_k1(int prec, const char* name) {
+    KernelEntry e{};
+    e.kind = KIND_K1;
+    e.prec = prec;
+    e.n = S::N;
+    e.f = F;
+    fill_sched<S>(e);
+    e.threads = F * S::TPF;
+    e.lds_bytes = lds_bytes<T, S, F, SPLIT>();
+    e.split = SPLIT;
+    e.name = name;
+    e.launch = [](const void* params, long long grid, void* stream) {
+        void* args[] = {const_cast<void*>(params)};
+        (void)hipLaunchKernel((const void*)k1_kernel<T, S, F, SPLIT>, dim3((unsigned)grid), dim3(F * S::TPF), args,
+                              lds_bytes<T, S, F, SPLIT>(), (hipStream_t)stream);
+    };
+    e.prepare = []() -> int {
+        return (int)hipFuncSetAttribute((const void*)k1_kernel<T, S, F, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds_bytes<T, S, F, SPLIT>());
+    };
+    return e;
+}
+template <class T, class S, int F, bool FIRST, bool SPLIT> KernelEntry make_k2(int prec, const char* name) {
+    KernelEntry e{};
+    e.kind = FIRST ? KIND_K2_FIRST : KIND_K2_LATER;
+    e.prec = prec;
+    e.n = S::N;
+    e.f = F;
+    fill_sched<S>(e);
+    e.threads = F * S::TPF;
+    e.lds_bytes = lds_bytes<T, S, F, SPLIT>();
+    e.split = SPLIT;
+    e.name = name;
+    e.launch = [](const void* params, long long grid, void* stream) {
+        void* args[] = {const_cast<void*>(params)};
+        (void)hipLaunchKernel((const void*)k2_kernel<T, S, F, FIRST, SPLIT>, dim3((unsigned)grid), dim3(F * S::TPF), args,
+                              lds_bytes<T, S, F, SPLIT>(), (hipStream_t)stream);
+    };
+    e.prepare = []() -> int {
+        return (int)hipFuncSetAttribute((const void*)k2_kernel<T, S, F, FIRST, SPLIT>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<T, S, F, SPLIT>());
+    };
+    return e;
+}
+#else
+// -------------------------------------------------------------------------------- host emulator
+template <class T, int NREG> struct HostExec {
+    int nt;
+    std::vector<cx<T>> regs;
+    explicit HostExec(int n) : nt(n), regs((size_t)n * NREG, cx<T>{0, 0}) {}
+    template <class Fn> void for_threads(Fn&& fn) {
+        for (int t = 0; t < nt; ++t) fn(t, regs.data() + (size_t)t * NREG);
+    }
+    void barrier() {}
+};
+template <class T, class S, int F, bool SPLIT> KernelEntry make_k1(int prec, const char* name) {
+    KernelEntry e{};
+    e.kind = KIND_K1;
+    e.prec = prec;
+    e.n = S::N;
+    e.f = F;
+    fill_sched<S>(e);
+    e.threads = F * S::TPF;
+    e.lds_bytes = lds_bytes<T, S, F, SPLIT>();
+    e.split = SPLIT;
+    e.name = name;
+    e.launch = [](const void* params, long long grid, void*) {
+        std::vector<char> lds(lds_bytes<T, S, F, SPLIT>() + 64, (char)0x5a);  // poisoned LDS
+        for (long long b = 0; b < grid; ++b) {
+            HostExec<T, regs_needed<S, SPLIT>()> ex(F * S::TPF);
+            k1_body<T, S, F, SPLIT>(ex, *(const K1Params<T>*)params, b, lds.data());
+        }
+    };
+    e.prepare = []() -> int { return 0; };
+    return e;
+}
+template <class T, class S, int F, bool FIRST, bool SPLIT> KernelEntry make_k2(int prec, const char* name) {
+    KernelEntry e{};
+    e.kind = FIRST ? KIND_K2_FIRST : KIND_K2_LATER;
+    e.prec = prec;
+    e.n = S::N;
+    e.f = F;
+    fill_sched<S>(e);
+    e.threads = F * S::TPF;
+    e.lds_bytes = lds_bytes<T, S, F, SPLIT>();
+    e.split = SPLIT;
+    e.name = name;
+    e.launch = [](const void* params, long long grid, void*) {
+        std::vector<char> lds(lds_bytes<T, S, F, SPLIT>() + 64, (char)0x5a);
+        for (long long b = 0; b < grid; ++b) {
+            HostExec<T, regs_needed<S, SPLIT>()> ex(F * S::TPF);
+            k2_body<T, S, F, FIRST, SPLIT>(ex, *(const K2Params<T>*)params, b, lds.data());
+        }
+    };
+    e.prepare = []() -> int { return 0; };
+    return e;
+}
+#endif
+
+#define MI_K1(T, PREC, F, SPLIT, ...) reg.push_back(make_k1<T, Sched<__VA_ARGS__>, F, SPLIT>(PREC, "k1<" #__VA_ARGS__ ">xF" #F))
+#define MI_K2(T, PREC, F, SPLIT, ...)                                                                  \
+    reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, true, SPLIT>(PREC, "k2first<" #__VA_ARGS__ ">xF" #F)); \
+    reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, false, SPLIT>(PREC, "k2later<" #__VA_ARGS__ ">xF" #F))
+
+}  // namespace mi355

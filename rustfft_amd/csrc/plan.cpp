@@ -1,0 +1,308 @@
+// Host side of the engine: plan construction (kernel selection + device tables) and execution.
+//
+// Plays the role the algorithm constructors play in the reference (twiddle precomputation in
+// Radix4::new_with_base, src/algorithm/radix4.rs:69-119; MixedRadix::new, mixed_radix.rs:53-126) and the
+// role of FftPlannerScalar::design_fft_for_len (src/plan.rs:312-323) for the GPU: the decisions differ
+// from the CPU recipes (they encode LDS capacity and HBM coalescing, not CPU caches) but the transform
+// they realise is the same unnormalised DFT.
+#include "plan.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <sstream>
+
+#include "backend.h"
+#include "kernels_params.h"
+
+namespace mi355 {
+
+static std::once_flag g_reg_once;
+std::vector<KernelEntry>& registry() {
+    static std::vector<KernelEntry> r;
+    return r;
+}
+void ensure_registry() {
+    std::call_once(g_reg_once, [] {
+        auto& r = registry();
+        register_k1_f32(r);
+        register_k1_f64(r);
+        register_k2_f32(r);
+        register_k2_f64(r);
+    });
+}
+
+static const KernelEntry* find_kernel(int kind, int prec, size_t n) {
+    for (auto& e : registry())
+        if (e.kind == kind && e.prec == prec && (size_t)e.n == n) return &e;
+    return nullptr;
+}
+
+// src/twiddles.rs:6-23 — forward twiddle, f64 angle, rounded to T by the caller
+static inline void twiddle_f64(size_t index, size_t fft_len, double* re, double* im) {
+    const double constant = -2.0 * 3.14159265358979323846264338327950288 / (double)fft_len;
+    const double angle = constant * (double)index;
+    *re = std::cos(angle);
+    *im = std::sin(angle);
+}
+template <class T> static void push_tw(std::vector<T>& v, size_t index, size_t fft_len) {
+    double re, im;
+    twiddle_f64(index, fft_len, &re, &im);
+    v.push_back((T)re);
+    v.push_back((T)im);
+}
+
+// sub-pass table of a workgroup schedule: pass p >= 1, layout [k-1][r], value w_{s_p R_p}^{r k}
+template <class T> static std::vector<T> build_subpass_twiddles(const KernelEntry& k) {
+    std::vector<T> t;
+    size_t s = k.radix[0];
+    for (int p = 1; p < k.np; ++p) {
+        const size_t R = k.radix[p];
+        for (size_t kk = 1; kk < R; ++kk)
+            for (size_t r = 0; r < s; ++r) push_tw<T>(t, r * kk, s * R);
+        s *= R;
+    }
+    return t;
+}
+
+Plan::~Plan() {
+    for (void* p : device_allocs) backend::dfree(p);
+    for (auto& kv : workspaces) backend::dfree(kv.second.ptr);
+}
+
+template <class T> static void* upload(Plan& plan, const std::vector<T>& host, int* rc) {
+    void* d = backend::dmalloc(host.size() * sizeof(T));
+    if (!d) {
+        *rc = MI355FFT_ERR_OUT_OF_MEMORY;
+        return nullptr;
+    }
+    plan.device_allocs.push_back(d);
+    if (!host.empty()) {
+        if (backend::h2d(d, host.data(), host.size() * sizeof(T), nullptr) || backend::sync(nullptr)) {
+            *rc = MI355FFT_ERR_HIP;
+            return nullptr;
+        }
+    }
+    return d;
+}
+
+// choose macro radices r_1..r_P (each with a FIRST and a LATER kernel) whose product is n:
+// fewest passes, then the most balanced split, larger radices first.
+static bool choose_macro_radices(int prec, size_t n, std::vector<size_t>& out) {
+    std::vector<size_t> avail;
+    for (auto& e : registry())
+        if (e.kind == KIND_K2_FIRST && e.prec == prec && find_kernel(KIND_K2_LATER, prec, e.n)) avail.push_back(e.n);
+    std::sort(avail.begin(), avail.end(), std::greater<size_t>());
+    avail.erase(std::unique(avail.begin(), avail.end()), avail.end());
+    std::vector<size_t> best, cur;
+    size_t best_max = 0;
+    for (int P = 2; P <= 5 && best.empty(); ++P) {
+        // enumerate non-increasing sequences of length P
+        struct Rec {
+            static void go(const std::vector<size_t>& av, size_t start, size_t rem, int left, std::vector<size_t>& cur,
+                           std::vector<size_t>& best, size_t& best_max) {
+                if (left == 0) {
+                    if (rem == 1 && (best.empty() || cur.front() < best_max)) {
+                        best = cur;
+                        best_max = cur.front();
+                    }
+                    return;
+                }
+                for (size_t i = start; i < av.size(); ++i) {
+                    if (rem % av[i]) continue;
+                    cur.push_back(av[i]);
+                    go(av, i, rem / av[i], left - 1, cur, best, best_max);
+                    cur.pop_back();
+                }
+            }
+        };
+        Rec::go(avail, 0, n, P, cur, best, best_max);
+    }
+    if (best.empty()) return false;
+    out = best;
+    return true;
+}
+
+template <class T> static int build_plan_t(Plan& plan) {
+    const size_t n = plan.len;
+    if (n <= 1) {
+        plan.kind = PLAN_TRIVIAL;
+        return MI355FFT_OK;
+    }
+    int rc = MI355FFT_OK;
+    if (const KernelEntry* k = find_kernel(KIND_K1, plan.prec, n)) {
+        if (k->prepare()) return MI355FFT_ERR_HIP;
+        plan.kind = PLAN_SINGLE;
+        PassDesc pd{};
+        pd.k = k;
+        pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(*k), &rc);
+        if (rc) return rc;
+        plan.passes.push_back(pd);
+        return MI355FFT_OK;
+    }
+    std::vector<size_t> radices;
+    if (choose_macro_radices(plan.prec, n, radices)) {
+        plan.kind = PLAN_MACRO;
+        size_t s = 1;
+        for (size_t p = 0; p < radices.size(); ++p) {
+            const size_t R = radices[p];
+            const KernelEntry* k = find_kernel(p == 0 ? KIND_K2_FIRST : KIND_K2_LATER, plan.prec, R);
+            if (k->prepare()) return MI355FFT_ERR_HIP;
+            const size_t M = n / R;
+            if (M % k->f != 0 || (p > 0 && s % k->f != 0)) return MI355FFT_ERR_UNSUPPORTED;
+            PassDesc pd{};
+            pd.k = k;
+            pd.m = (long long)M;
+            pd.s = (long long)s;
+            pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(*k), &rc);
+            if (rc) return rc;
+            if (p > 0) {
+                // two-level table for w_Q^e, Q = S R, e < Q:  e = (e >> h) << h | (e & mask)
+                const size_t Q = s * R;
+                int bits = 0;
+                while (((size_t)1 << bits) < Q) ++bits;
+                const int h = (bits + 1) / 2;
+                std::vector<T> lo, hi;
+                for (size_t e = 0; e < ((size_t)1 << h); ++e) push_tw<T>(lo, e, Q);
+                for (size_t q = 0; q <= ((Q - 1) >> h); ++q) push_tw<T>(hi, q << h, Q);
+                pd.hshift = h;
+                pd.lmask = (int)(((size_t)1 << h) - 1);
+                pd.d_tlo = upload<T>(plan, lo, &rc);
+                if (rc) return rc;
+                pd.d_thi = upload<T>(plan, hi, &rc);
+                if (rc) return rc;
+            }
+            plan.passes.push_back(pd);
+            s *= R;
+        }
+        return MI355FFT_OK;
+    }
+    return MI355FFT_ERR_UNSUPPORTED;
+}
+
+int build_plan(Plan& plan) {
+    ensure_registry();
+    return plan.prec == 32 ? build_plan_t<float>(plan) : build_plan_t<double>(plan);
+}
+
+std::string Plan::describe() const {
+    std::ostringstream s;
+    if (kind == PLAN_TRIVIAL) s << "trivial(len=" << len << ")";
+    for (size_t i = 0; i < passes.size(); ++i) s << (i ? " -> " : "") << passes[i].k->name;
+    return s.str();
+}
+
+// ---- workspace -----------------------------------------------------------------------------------------
+void* Plan::workspace_for(void* stream, size_t bytes) {
+    std::lock_guard<std::mutex> g(ws_mutex);
+    Workspace& w = workspaces[stream];
+    if (w.bytes < bytes) {
+        if (w.ptr) {
+            backend::sync(stream);
+            backend::dfree(w.ptr);
+        }
+        w.ptr = backend::dmalloc(bytes);
+        w.bytes = w.ptr ? bytes : 0;
+    }
+    return w.ptr;
+}
+
+// ---- execution -------------------------------------------------------------------------------------------
+template <class T>
+static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, size_t batch, void* stream, Tracer* tr) {
+    const PassDesc& pd = plan.passes[pi];
+    const KernelEntry& k = *pd.k;
+    const bool inverse = plan.direction == MI355FFT_INVERSE;
+    long long grid;
+    if (tr) tr->before((int)pi, stream);
+    if (k.kind == KIND_K1) {
+        K1Params<T> p{};
+        p.in = (const cx<T>*)in;
+        p.out = (cx<T>*)out;
+        p.tw = (const cx<T>*)pd.d_tw;
+        p.batch = (long long)batch;
+        p.sgn = inverse ? (T)-1 : (T)1;
+        grid = (long long)((batch + k.f - 1) / k.f);
+        k.launch(&p, grid, stream);
+    } else {
+        K2Params<T> p{};
+        p.in = (const cx<T>*)in;
+        p.out = (cx<T>*)out;
+        p.tw = (const cx<T>*)pd.d_tw;
+        p.tlo = (const cx<T>*)pd.d_tlo;
+        p.thi = (const cx<T>*)pd.d_thi;
+        p.hshift = pd.hshift;
+        p.lmask = pd.lmask;
+        p.n = (long long)plan.len;
+        p.m = pd.m;
+        p.s = pd.s;
+        p.batch = (long long)batch;
+        p.tiles_per_fft = pd.m / k.f;
+        p.sgn_in = (inverse && pi == 0) ? (T)-1 : (T)1;
+        p.sgn_out = (inverse && pi + 1 == plan.passes.size()) ? (T)-1 : (T)1;
+        grid = (long long)batch * p.tiles_per_fft;
+        k.launch(&p, grid, stream);
+    }
+    if (tr) tr->after((int)pi, stream);
+    return backend::check_launch() ? MI355FFT_ERR_HIP : MI355FFT_OK;
+}
+
+// mode: 0 in-place (in == out), 1 out-of-place (input may be clobbered), 2 immutable input
+template <class T> static int execute_t(Plan& plan, const void* in, void* out, size_t batch, void* stream, int mode, Tracer* tr) {
+    const size_t esz = 2 * sizeof(T);
+    const size_t n = plan.len;
+    if (batch == 0 || n == 0) return MI355FFT_OK;
+    if (plan.kind == PLAN_TRIVIAL) {  // len 1: the DFT is the identity (reference plans Dft(1), src/plan.rs:313-314)
+        if (in != out && backend::d2d(out, in, batch * n * esz, stream)) return MI355FFT_ERR_HIP;
+        return MI355FFT_OK;
+    }
+    const size_t P = plan.passes.size();
+    if (P == 1) return launch_pass<T>(plan, 0, in, out, batch, stream, tr);
+
+    // Buffer rotation.  Every pass but the last is out-of-place; the last one may run in place.
+    //   in-place : buf -> ws -> buf -> ws ... -> buf
+    //   oop      : in -> out -> in -> out ... -> out   (clobbers `in`, which the trait allows)
+    //   immutable: in -> {out, ws alternating, ending ...-> out -> out}
+    size_t chunk = plan.chunk_batch ? plan.chunk_batch : batch;
+    if (chunk > batch) chunk = batch;
+    const bool need_ws = (mode == 0) || (mode == 2 && P >= 3);
+    char* ws = nullptr;
+    if (need_ws) {
+        ws = (char*)plan.workspace_for(stream, chunk * n * esz);
+        if (!ws) return MI355FFT_ERR_OUT_OF_MEMORY;
+    } else {
+        chunk = batch;
+    }
+    for (size_t c0 = 0; c0 < batch; c0 += chunk) {
+        const size_t cb = std::min(chunk, batch - c0);
+        const char* cin = (const char*)in + c0 * n * esz;
+        char* cout = (char*)out + c0 * n * esz;
+        char *A, *B;
+        if (mode == 0) {
+            A = ws;
+            B = cout;
+        } else if (mode == 1) {
+            A = cout;
+            B = (char*)cin;
+        } else {
+            A = (P % 2 == 0) ? cout : ws;
+            B = (P % 2 == 0) ? ws : cout;
+        }
+        const char* src = cin;
+        for (size_t p = 0; p < P; ++p) {
+            char* dstp = (p + 1 == P) ? cout : ((p % 2 == 0) ? A : B);
+            int rc = launch_pass<T>(plan, p, src, dstp, cb, stream, tr);
+            if (rc) return rc;
+            src = dstp;
+        }
+    }
+    return MI355FFT_OK;
+}
+
+int execute(Plan& plan, const void* in, void* out, size_t batch, void* stream, int mode, Tracer* tr) {
+    return plan.prec == 32 ? execute_t<float>(plan, in, out, batch, stream, mode, tr)
+                           : execute_t<double>(plan, in, out, batch, stream, mode, tr);
+}
+
+}  // namespace mi355

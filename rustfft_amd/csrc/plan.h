@@ -1,0 +1,60 @@
+// Plan object behind `mi355fft_plan` (include/mi355fft.h).
+#pragma once
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355fft.h"
+#include "registry.h"
+
+namespace mi355 {
+
+enum PlanKind { PLAN_TRIVIAL = 0, PLAN_SINGLE = 1, PLAN_MACRO = 2 };
+
+struct PassDesc {
+    const KernelEntry* k;
+    void* d_tw;   // sub-pass twiddles of the workgroup transform
+    void* d_tlo;  // two-level inter-pass twiddle tables (macro passes after the first)
+    void* d_thi;
+    int hshift, lmask;
+    long long m, s;  // M = N / R and S = product of the earlier macro radices
+};
+
+struct Workspace {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+};
+
+// per-kernel event hooks for mi355fft_profile_inplace_dev
+struct Tracer {
+    virtual ~Tracer() {}
+    virtual void before(int pass, void* stream) = 0;
+    virtual void after(int pass, void* stream) = 0;
+};
+
+struct Plan {
+    size_t len = 0;
+    int direction = 0, prec = 32;
+    int kind = PLAN_TRIVIAL;
+    std::vector<PassDesc> passes;
+    std::vector<void*> device_allocs;
+    size_t chunk_batch = 0;
+    std::mutex ws_mutex;
+    std::map<void*, Workspace> workspaces;  // one HBM workspace per stream
+    std::mutex host_mutex;                  // serialises the host-slice staging path
+    Workspace stage_a, stage_b;
+
+    ~Plan();
+    std::string describe() const;
+    void* workspace_for(void* stream, size_t bytes);
+};
+
+int build_plan(Plan& plan);
+int execute(Plan& plan, const void* in, void* out, size_t batch, void* stream, int mode, Tracer* tr);
+
+}  // namespace mi355
+
+struct mi355fft_plan {
+    mi355::Plan p;
+};

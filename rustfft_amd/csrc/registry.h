@@ -1,0 +1,44 @@
+// Kernel registry: one KernelEntry per compiled (schedule, tile, precision) instantiation.  The host
+// planner (plan.cpp) picks entries by length; `launch` hides whether the body runs as a gfx950 kernel
+// (HIP build) or under the host emulator of the kernel bodies (tests/emu build).
+#pragma once
+#include <cstddef>
+#include <vector>
+
+namespace mi355 {
+
+enum KernelKind { KIND_K1 = 1, KIND_K2_FIRST = 2, KIND_K2_LATER = 3, KIND_RADER = 4, KIND_BLUESTEIN = 5 };
+
+struct KernelEntry {
+    int kind;
+    int prec;  // 32 / 64
+    int n;     // transform length handled by one workgroup sequence (N for K1, R for K2)
+    int f;     // sequences per workgroup (K1) / tile width in columns (K2)
+    int tpf, np, radix[8];
+    int threads;
+    size_t lds_bytes;
+    int tw_total;  // entries in the sub-pass twiddle table
+    bool split;
+    int aux;  // kind-specific (Rader/Bluestein: inner length)
+    const char* name;
+    void (*launch)(const void* params, long long grid, void* stream);
+    int (*prepare)();  // one-time setup (dynamic-LDS attribute); returns 0 on success
+};
+
+std::vector<KernelEntry>& registry();
+void ensure_registry();  // populate once (thread-safe)
+
+// each kernels_*.{hip,cpp} translation unit contributes through one of these
+void register_k1_f32(std::vector<KernelEntry>&);
+void register_k1_f64(std::vector<KernelEntry>&);
+void register_k2_f32(std::vector<KernelEntry>&);
+void register_k2_f64(std::vector<KernelEntry>&);
+
+template <class S> inline void fill_sched(KernelEntry& e) {
+    e.tpf = S::TPF;
+    e.np = S::NP;
+    for (int i = 0; i < 8; ++i) e.radix[i] = i < S::NP ? S::R[i] : 0;
+    e.tw_total = S::tw_total();
+}
+
+}  // namespace mi355

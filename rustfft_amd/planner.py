@@ -1,0 +1,238 @@
+"""Python mirror of the reference's `FftPlanner` / `Fft<T>` surface for the HIP back-end.
+
+Names, argument meaning and error behaviour follow the reference so the parity tests read like the
+reference's own tests:
+  FftPlanner::new / plan_fft / plan_fft_forward / plan_fft_inverse      src/plan.rs:72-126
+  Fft::process / process_with_scratch / process_outofplace_with_scratch /
+       process_immutable_with_scratch / get_*_scratch_len               src/lib.rs:184-278
+  Length::len, Direction::fft_direction                                 src/lib.rs:140-177
+  panic messages                                                         src/common.rs:13-104  (-> FftPanic)
+Buffers may be numpy arrays (host slices: the literal drop-in, staged through PCIe) or torch CUDA tensors
+(HBM-resident: the measured path, asynchronous on torch's current stream).
+"""
+import ctypes
+import enum
+
+import numpy as np
+
+from . import _native
+
+SCRATCH_INPLACE, SCRATCH_OUTOFPLACE, SCRATCH_IMMUTABLE = 0, 1, 2
+
+
+class FftDirection(enum.IntEnum):  # src/lib.rs:146-171
+    Forward = 0
+    Inverse = 1
+
+    def opposite_direction(self):
+        return FftDirection.Inverse if self == FftDirection.Forward else FftDirection.Forward
+
+
+class FftPanic(RuntimeError):
+    """A reference `panic!` (src/common.rs:13-104), carrying the reference's message."""
+
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+
+
+def _precision(dtype):
+    dtype = np.dtype(dtype)
+    if dtype in (np.dtype(np.complex64), np.dtype(np.float32)):
+        return 32
+    if dtype in (np.dtype(np.complex128), np.dtype(np.float64)):
+        return 64
+    raise TypeError("FftNum must be f32 or f64 (complex64 / complex128 buffers)")
+
+
+def device_count(lib=None):
+    return (lib or _native.load()).mi355fft_device_count()
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class Fft:
+    """`Arc<dyn Fft<T>>` for the HIP back-end."""
+
+    def __init__(self, lib, handle, dtype):
+        self._lib = lib
+        self._h = handle
+        self.dtype = np.dtype(dtype)
+        self._len = lib.mi355fft_plan_len(handle)
+        self._dir = FftDirection(lib.mi355fft_plan_direction(handle))
+
+    def __del__(self):
+        try:
+            self._lib.mi355fft_plan_destroy(self._h)
+        except Exception:
+            pass
+
+    # Length / Direction
+    def len(self):
+        return self._len
+
+    def fft_direction(self):
+        return self._dir
+
+    # scratch queries (src/lib.rs:262-277): 0 — the workspace lives in HBM and belongs to the plan
+    def get_inplace_scratch_len(self):
+        return self._lib.mi355fft_scratch_len(self._h, SCRATCH_INPLACE)
+
+    def get_outofplace_scratch_len(self):
+        return self._lib.mi355fft_scratch_len(self._h, SCRATCH_OUTOFPLACE)
+
+    def get_immutable_scratch_len(self):
+        return self._lib.mi355fft_scratch_len(self._h, SCRATCH_IMMUTABLE)
+
+    def describe(self):
+        buf = ctypes.create_string_buffer(1024)
+        self._lib.mi355fft_plan_describe(self._h, buf, 1024)
+        return buf.value.decode()
+
+    def kernel_names(self):
+        n = self._lib.mi355fft_plan_num_kernels(self._h)
+        return [self._lib.mi355fft_plan_kernel_name(self._h, i).decode() for i in range(n)]
+
+    def set_chunk_batch(self, chunk_batch):
+        self._check(self._lib.mi355fft_plan_set_chunk_batch(self._h, int(chunk_batch)))
+
+    # ---- helpers -------------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            raise FftPanic(rc, self._lib.mi355fft_last_error().decode() or self._lib.mi355fft_strerror(rc).decode())
+
+    def _host(self, a, writable):
+        if not isinstance(a, np.ndarray):
+            raise TypeError("expected a numpy array or a torch CUDA tensor")
+        if a.dtype != self.dtype:
+            raise TypeError(f"buffer dtype {a.dtype} does not match the plan ({self.dtype})")
+        if not a.flags.c_contiguous or (writable and not a.flags.writeable):
+            raise ValueError("buffers must be C-contiguous (and writable where the trait takes &mut)")
+        return ctypes.c_void_p(a.ctypes.data if a.size else 0), a.size
+
+    def _dev(self, t):
+        import torch
+
+        want = torch.complex64 if self.dtype == np.complex64 else torch.complex128
+        if t.dtype != want or not t.is_cuda or not t.is_contiguous():
+            raise TypeError("device buffers must be contiguous CUDA tensors of the plan's complex dtype")
+        return ctypes.c_void_p(t.data_ptr()), t.numel()
+
+    @staticmethod
+    def _stream():
+        import torch
+
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _validate_dev(self, n_in, n_out=None):
+        # same outcomes as the host path (src/fft_helper.rs + src/common.rs), raised before any launch
+        n = self._len
+        if n == 0:
+            return 0
+        if n_out is not None and n_in != n_out:
+            raise FftPanic(5, "Provided FFT input buffer and output buffer must have the same length. "
+                              f"Got input.len() = {n_in}, output.len() = {n_out}")
+        return n_in // n
+
+    def _tail_error(self, n_in):
+        n = self._len
+        if n and n_in % n:
+            if n_in < n:
+                raise FftPanic(2, f"Provided FFT buffer was too small. Expected len = {n}, got len = {n_in}")
+            raise FftPanic(3, f"Input FFT buffer must be a multiple of FFT length. Expected multiple of {n}, got len = {n_in}")
+
+    # ---- the trait methods ------------------------------------------------------------------------------
+    def process(self, buffer):
+        """Fft::process (src/lib.rs:195-198)."""
+        self.process_with_scratch(buffer, None)
+
+    def process_with_scratch(self, buffer, scratch=None):
+        """Fft::process_with_scratch (src/lib.rs:211)."""
+        if _is_torch(buffer):
+            p, n = self._dev(buffer)
+            batch = self._validate_dev(n)
+            if batch:
+                self._check(self._lib.mi355fft_process_inplace_dev(self._h, p, batch, self._stream()))
+            self._tail_error(n)
+            return
+        p, n = self._host(buffer, True)
+        sp, sn = (None, 0) if scratch is None else self._host(scratch, True)
+        self._check(self._lib.mi355fft_process_inplace_host(self._h, p, n, sp, sn))
+
+    def process_outofplace_with_scratch(self, input, output, scratch=None):
+        """Fft::process_outofplace_with_scratch (src/lib.rs:231) — `input` may be clobbered."""
+        if _is_torch(input):
+            pi, ni = self._dev(input)
+            po, no = self._dev(output)
+            batch = self._validate_dev(ni, no)
+            if batch:
+                self._check(self._lib.mi355fft_process_outofplace_dev(self._h, pi, po, batch, self._stream()))
+            self._tail_error(ni)
+            return
+        pi, ni = self._host(input, True)
+        po, no = self._host(output, True)
+        sp, sn = (None, 0) if scratch is None else self._host(scratch, True)
+        self._check(self._lib.mi355fft_process_outofplace_host(self._h, pi, ni, po, no, sp, sn))
+
+    def process_immutable_with_scratch(self, input, output, scratch=None):
+        """Fft::process_immutable_with_scratch (src/lib.rs:250) — `input` is preserved."""
+        if _is_torch(input):
+            pi, ni = self._dev(input)
+            po, no = self._dev(output)
+            batch = self._validate_dev(ni, no)
+            if batch:
+                self._check(self._lib.mi355fft_process_immutable_dev(self._h, pi, po, batch, self._stream()))
+            self._tail_error(ni)
+            return
+        pi, ni = self._host(input, False)
+        po, no = self._host(output, True)
+        sp, sn = (None, 0) if scratch is None else self._host(scratch, True)
+        self._check(self._lib.mi355fft_process_immutable_host(self._h, pi, ni, po, no, sp, sn))
+
+    # ---- measurement hook --------------------------------------------------------------------------------
+    def profile_kernels(self, buffer, reps=5):
+        """Mean milliseconds of each kernel of the in-place transform (HIP events on torch's current stream)."""
+        p, n = self._dev(buffer)
+        batch = n // self._len
+        nk = self._lib.mi355fft_plan_num_kernels(self._h)
+        ms = (ctypes.c_float * max(nk, 1))()
+        self._check(self._lib.mi355fft_profile_inplace_dev(self._h, p, batch, self._stream(), reps, ms, nk))
+        return [float(ms[i]) for i in range(nk)]
+
+
+class FftPlannerHip:
+    """`FftPlannerHip<T>`: the back-end planner a `ChosenFftPlanner::Hip` arm would hold (pattern:
+    FftPlannerAvx, src/avx/avx_planner.rs:113-192).  Construction fails (the `Err(())` of the reference's
+    SIMD planners) when no gfx950 device is visible."""
+
+    def __init__(self, dtype=np.complex64, device=0, lib=None):
+        self._lib = lib or _native.load()
+        self.dtype = np.dtype(dtype)
+        self._prec = _precision(dtype)
+        rc = self._lib.mi355fft_init(device)
+        if rc != 0:
+            raise FftPanic(rc, self._lib.mi355fft_last_error().decode() or "no gfx950 device")
+        self._cache = {}  # src/fft_cache.rs:5-39 — one instance per (len, direction)
+
+    def plan_fft(self, len, direction):
+        direction = FftDirection(direction)
+        key = (int(len), direction)
+        if key not in self._cache:
+            h = ctypes.c_void_p()
+            rc = self._lib.mi355fft_plan_create(int(len), int(direction), self._prec, ctypes.byref(h))
+            if rc != 0:
+                raise FftPanic(rc, self._lib.mi355fft_last_error().decode() or self._lib.mi355fft_strerror(rc).decode())
+            self._cache[key] = Fft(self._lib, h, self.dtype)
+        return self._cache[key]
+
+    def plan_fft_forward(self, len):
+        return self.plan_fft(len, FftDirection.Forward)
+
+    def plan_fft_inverse(self, len):
+        return self.plan_fft(len, FftDirection.Inverse)
+
+
+# `FftPlanner::new()` picks the best available back-end (src/plan.rs:72-94); here the only back-end is HIP.
+FftPlanner = FftPlannerHip

@@ -55,14 +55,14 @@ def check_fft_algorithm(fft, length, direction, reference=None, n=3):
     entry points, each again with scratch pre-filled with (100,100) ("dirty scratch")."""
     assert fft.len() == length, "Algorithm reported incorrect size"
     assert fft.fft_direction() == direction, "Algorithm reported incorrect FFT direction"
-    dtype = fft.dtype
+    dtype = np.dtype(fft.dtype)
     x = random_signal(length * n, dtype)
     if reference is None:
         expected = numpy_fft(x, length, direction == 1) if length > 0 else x.copy()
     else:
         expected = x.copy()
         reference.process(expected)
-    dirty = dtype(100 + 100j)
+    dirty = np.dtype(dtype).type(100 + 100j)
 
     buf = x.copy()
     fft.process(buf)

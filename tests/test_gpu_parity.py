@@ -1,0 +1,193 @@
+"""Parity tests proper (-m gpu): the HIP path, called through the C ABI (include/mi355fft.h) via the
+rustfft_amd host mirror, against the oracle (oracle/rustfft_scalar.hpp, RustFFT's scalar path) on the same
+seeded inputs.  Tolerance = the reference's own (tests/accuracy.rs:30-37): mean |a - b| < 0.1 on inputs
+re, im ~ U[0,10); in addition a relative-L2 bound vs a float64 reference is asserted (SURVEY App. C:
+O(eps log2 N): 5e-6 for f32, 1e-13 for f64)."""
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import check_fft_algorithm, compare_vectors, mean_abs_err, numpy_fft, random_signal, rel_l2, zero_mean_signal
+
+pytestmark = pytest.mark.gpu
+
+REL = {np.dtype(np.complex64): 5e-6, np.dtype(np.complex128): 1e-13}
+
+
+@pytest.fixture(scope="module")
+def planners():
+    import torch
+
+    assert torch.cuda.is_available(), "-m gpu tests need an MI355X"
+    import rustfft_amd
+
+    return {np.dtype(np.complex64): rustfft_amd.FftPlanner(np.complex64), np.dtype(np.complex128): rustfft_amd.FftPlanner(np.complex128)}
+
+
+def _native_loaded():
+    return any("libmi355fft.so" in line for line in open("/proc/self/maps"))
+
+
+def test_native_library_is_the_one_running(planners):
+    assert _native_loaded(), "the HIP extension must be loaded in-process (no fallback path exists)"
+    import rustfft_amd
+
+    assert rustfft_amd.device_count() >= 1
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_check_fft_algorithm_pow2(planners, oracle, dtype):
+    """src/test_utils.rs:70-209 on every planned power of two up to 2^18 (host-slice entry points:
+    process, process_with_scratch, process_outofplace_with_scratch, process_immutable_with_scratch)."""
+    planner = planners[np.dtype(dtype)]
+    for n in [0, 1] + [1 << p for p in range(1, 19)]:
+        for d in (0, 1):
+            fft = planner.plan_fft(n, d)
+            check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=3 if n < (1 << 16) else 2)
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_relative_error_vs_float64(planners, dtype):
+    planner = planners[np.dtype(dtype)]
+    for p in (4, 7, 10, 12, 13, 16, 20, 21, 22):
+        n = 1 << p
+        for d in (0, 1):
+            x = zero_mean_signal(n * 2, dtype)
+            y = x.copy()
+            planner.plan_fft(n, d).process(y)
+            assert rel_l2(y, numpy_fft(x, n, d == 1)) < REL[np.dtype(dtype)], (n, d)
+
+
+def test_config1_n1024_plumbing(planners, oracle):
+    """BASELINE config 1: single forward FFT, N = 1024, Complex<f32>."""
+    x = random_signal(1024, np.complex64)
+    y = x.copy()
+    planners[np.dtype(np.complex64)].plan_fft_forward(1024).process(y)
+    want = x.copy()
+    oracle.plan(np.complex64, 1024, 0).process(want)
+    assert compare_vectors(want, y) and mean_abs_err(want, y) < 1e-3
+
+
+def test_config2_device_resident_2p20(planners, oracle):
+    """BASELINE config 2 shape (N = 2^20 f32, forward + inverse) on HBM-resident data: 8 sampled rows vs the
+    oracle's Radix4 + numpy c128, and the round trip ifft(fft(x)) = N x on every row of a 64-row batch."""
+    import torch
+
+    n, batch = 1 << 20, 64
+    planner = planners[np.dtype(np.complex64)]
+    fwd, inv = planner.plan_fft_forward(n), planner.plan_fft_inverse(n)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x52555354 + 2)
+    x = torch.empty(batch * n, dtype=torch.complex64, device="cuda")
+    torch.view_as_real(x).uniform_(0.0, 10.0, generator=g)
+    y = x.clone()
+    fwd.process(y)
+    torch.cuda.synchronize()
+    ref = oracle.plan(np.complex64, n, 0)
+    for row in (0, 1, 7, 13, 31, 32, 62, 63):
+        xr = x[row * n:(row + 1) * n].cpu().numpy()
+        got = y[row * n:(row + 1) * n].cpu().numpy()
+        want = xr.copy()
+        ref.process(want)
+        assert compare_vectors(want, got), row
+        assert rel_l2(got, numpy_fft(xr, n, False)) < REL[np.dtype(np.complex64)], row
+    inv.process(y)
+    torch.cuda.synchronize()
+    err = (y / n - x).abs().mean().item()
+    assert err < 1e-4, err
+    # out-of-place and immutable device entry points agree bit-for-bit with the in-place one
+    a = x.clone()
+    out = torch.empty_like(x)
+    fwd.process_immutable_with_scratch(a, out)
+    assert torch.equal(a, x)
+    z = x.clone()
+    fwd.process(z)
+    assert torch.equal(out, z)
+    out2 = torch.empty_like(x)
+    fwd.process_outofplace_with_scratch(a, out2)
+    assert torch.equal(out2, z)
+
+
+def test_full_size_properties_2p22(planners):
+    """N = 2^22 (config 5's length, three-pass plan): impulse -> complex exponential, constant -> delta,
+    Parseval, on a 16-row batch."""
+    import torch
+
+    n, batch = 1 << 22, 16
+    planner = planners[np.dtype(np.complex64)]
+    fwd = planner.plan_fft_forward(n)
+    x = torch.zeros(batch * n, dtype=torch.complex64, device="cuda")
+    xs = x.view(batch, n)
+    xs[0, 5] = 1.0
+    xs[1, :] = 1.0
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    torch.view_as_real(xs[2:]).uniform_(-1.0, 1.0, generator=g)
+    energy_in = (xs[2:].abs().double() ** 2).sum(dim=1)
+    fwd.process(x)
+    torch.cuda.synchronize()
+    k = torch.arange(n, device="cuda", dtype=torch.float64)
+    want = torch.exp(-2j * np.pi * 5 * k / n)
+    assert (xs[0].to(torch.complex128) - want).abs().max().item() < 1e-5
+    assert abs(xs[1, 0].item() - n) < 1e-1 * 1e-3 * n and xs[1, 1:].abs().max().item() < 1e-2
+    energy_out = (xs[2:].abs().double() ** 2).sum(dim=1) / n
+    assert torch.allclose(energy_in, energy_out, rtol=1e-5)
+
+
+def test_chunked_workspace_identical(planners):
+    import torch
+
+    n, batch = 1 << 14, 37
+    fft = planners[np.dtype(np.complex64)].plan_fft_forward(n)
+    x = torch.from_numpy(random_signal(n * batch, np.complex64)).cuda()
+    a = x.clone()
+    fft.process(a)
+    fft.set_chunk_batch(5)
+    b = x.clone()
+    fft.process(b)
+    fft.set_chunk_batch(0)
+    assert torch.equal(a, b)
+
+
+def test_error_paths(planners):
+    import rustfft_amd
+
+    f = planners[np.dtype(np.complex64)].plan_fft_forward(256)
+    with pytest.raises(rustfft_amd.FftPanic, match="Provided FFT buffer was too small. Expected len = 256, got len = 10"):
+        f.process(np.zeros(10, np.complex64))
+    with pytest.raises(rustfft_amd.FftPanic, match="must be a multiple of FFT length"):
+        f.process(np.zeros(300, np.complex64))
+    with pytest.raises(rustfft_amd.FftPanic, match="must have the same length"):
+        f.process_immutable_with_scratch(np.zeros(256, np.complex64), np.zeros(512, np.complex64))
+    f.process(np.zeros(0, np.complex64))
+    import torch
+
+    with pytest.raises(rustfft_amd.FftPanic, match="must be a multiple of FFT length"):
+        f.process(torch.zeros(300, dtype=torch.complex64, device="cuda"))
+    with pytest.raises(rustfft_amd.FftPanic, match="no GPU plan"):
+        planners[np.dtype(np.complex64)].plan_fft_forward(3 * 1000003)
+
+
+def test_concurrent_process_on_one_plan(planners, oracle):
+    """examples/concurrency.rs:9-30: one Arc<dyn Fft> shared by several threads, each with its own buffer."""
+    n = 4096
+    fft = planners[np.dtype(np.complex64)].plan_fft_forward(n)
+    ref = oracle.plan(np.complex64, n, 0)
+    results, inputs = {}, {t: random_signal(n * 3, np.complex64, seed=100 + t) for t in range(4)}
+
+    def work(t):
+        buf = inputs[t].copy()
+        for _ in range(3):
+            b2 = inputs[t].copy()
+            fft.process(b2)
+            buf = b2
+        results[t] = buf
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    for t in range(4):
+        want = inputs[t].copy()
+        ref.process(want)
+        assert compare_vectors(want, results[t])

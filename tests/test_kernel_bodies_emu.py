@@ -1,0 +1,129 @@
+"""Kernel-body checks without a GPU.  tests/emu compiles the SAME kernel bodies (rustfft_amd/csrc/*.h,
+*.hip) for the host with an executor that runs every GPU thread of a workgroup phase by phase
+(launch.h, MI355_EMU), behind the same C ABI.  This validates all index arithmetic, LDS exchange
+patterns, twiddle tables, buffer rotation and the API semantics against the oracle; it says nothing about
+performance and is never loaded by the product."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import check_fft_algorithm, compare_vectors, numpy_fft, random_signal, rel_l2, zero_mean_signal
+
+EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+
+
+@pytest.fixture(scope="module")
+def emu_planner():
+    subprocess.check_call(["make", "-C", EMU_DIR, "-j", "8", "-s"])
+    import rustfft_amd
+    from rustfft_amd import _native
+
+    lib = _native.load(os.path.join(EMU_DIR, "libmi355fft_emu.so"))
+    return lambda dtype: rustfft_amd.FftPlannerHip(dtype, lib=lib)
+
+
+POW2_SINGLE = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096]
+POW2_MULTI = [1 << 13, 1 << 14, 1 << 15, 1 << 16, 1 << 17, 1 << 18]
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_single_kernel_sizes_all_api_modes(emu_planner, oracle, dtype):
+    planner = emu_planner(dtype)
+    for n in [0, 1] + POW2_SINGLE:
+        for d in (0, 1):
+            fft = planner.plan_fft(n, d)
+            ref = oracle.plan(dtype, n, d)  # the reference's scalar path (Radix4 over Butterfly8/16 etc.)
+            check_fft_algorithm(fft, n, d, reference=ref)
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_multi_pass_sizes_all_api_modes(emu_planner, oracle, dtype):
+    planner = emu_planner(dtype)
+    for n in POW2_MULTI:
+        d = n.bit_length() % 2
+        fft = planner.plan_fft(n, d)
+        assert "k2first" in fft.describe() and "k2later" in fft.describe()
+        check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=2)
+
+
+def test_config2_and_three_pass_shapes(emu_planner, oracle):
+    """BASELINE config 2 (N = 2^20, f32, forward + inverse) and config 5's N = 2^22, small batch."""
+    planner = emu_planner(np.complex64)
+    for n, batch in ((1 << 20, 2), (1 << 22, 1)):
+        x = zero_mean_signal(n * batch, np.complex64)
+        fwd, inv = planner.plan_fft_forward(n), planner.plan_fft_inverse(n)
+        y = x.copy()
+        fwd.process(y)
+        want = x.copy()
+        oracle.plan(np.complex64, n, 0).process(want)
+        assert compare_vectors(want, y)
+        assert rel_l2(y, numpy_fft(x, n, False)) < 2e-6
+        inv.process(y)  # round trip: ifft(fft(x)) == N x
+        assert rel_l2(y / n, x) < 2e-6
+    assert planner.plan_fft_forward(1 << 22).describe().count("k2") == 3
+
+
+def test_chunked_workspace_matches_unchunked(emu_planner):
+    planner = emu_planner(np.complex64)
+    n, batch = 1 << 13, 7
+    x = random_signal(n * batch, np.complex64)
+    fft = planner.plan_fft_forward(n)
+    a = x.copy()
+    fft.process(a)
+    fft.set_chunk_batch(2)
+    b = x.copy()
+    fft.process(b)
+    fft.set_chunk_batch(0)
+    assert np.array_equal(a, b)
+
+
+def test_validation_semantics(emu_planner):
+    """src/common.rs:13-104 messages; partial trailing chunk reported AFTER the complete chunks ran
+    (src/array_utils.rs:164-176); empty buffer accepted; len 0 is a no-op (src/fft_helper.rs:16-18)."""
+    import rustfft_amd
+
+    planner = emu_planner(np.complex64)
+    f = planner.plan_fft_forward(64)
+    with pytest.raises(rustfft_amd.FftPanic, match="Provided FFT buffer was too small. Expected len = 64, got len = 10"):
+        f.process(np.zeros(10, np.complex64))
+    x = random_signal(64 * 2 + 5, np.complex64)
+    y = x.copy()
+    with pytest.raises(rustfft_amd.FftPanic, match="must be a multiple of FFT length. Expected multiple of 64, got len = 133"):
+        f.process(y)
+    assert compare_vectors(y[:128], numpy_fft(x[:128], 64, False)) and np.array_equal(y[128:], x[128:])
+    with pytest.raises(rustfft_amd.FftPanic, match=r"Got input.len\(\) = 64, output.len\(\) = 128"):
+        f.process_outofplace_with_scratch(np.zeros(64, np.complex64), np.zeros(128, np.complex64))
+    f.process(np.zeros(0, np.complex64))
+    planner.plan_fft_forward(0).process(np.zeros(0, np.complex64))
+    one = random_signal(3, np.complex64)
+    o2 = one.copy()
+    planner.plan_fft_forward(1).process(o2)
+    assert np.array_equal(one, o2)
+    assert f.get_inplace_scratch_len() == 0 and f.get_outofplace_scratch_len() == 0 and f.get_immutable_scratch_len() == 0
+    assert f.len() == 64 and f.fft_direction() == rustfft_amd.FftDirection.Forward
+    assert planner.plan_fft_forward(64) is f and planner.plan_fft_inverse(64) is not f  # fft_cache.rs:5-39
+
+
+def test_unsupported_length_fails_loudly(emu_planner):
+    import rustfft_amd
+
+    with pytest.raises(rustfft_amd.FftPanic, match="no GPU plan"):
+        emu_planner(np.complex64).plan_fft_forward(3 * 1000003)
+
+
+def test_linearity_and_shift(emu_planner):
+    planner = emu_planner(np.complex128)
+    n = 1 << 14
+    fft = planner.plan_fft_forward(n)
+    a, b = zero_mean_signal(n, np.complex128, 1), zero_mean_signal(n, np.complex128, 2)
+    fa, fb, fc = a.copy(), b.copy(), (2.5 * a - 1j * b)
+    fft.process(fa)
+    fft.process(fb)
+    fft.process(fc)
+    assert rel_l2(fc, 2.5 * fa - 1j * fb) < 1e-13
+    imp = np.zeros(n, np.complex128)
+    imp[3] = 1.0
+    fft.process(imp)
+    assert rel_l2(imp, np.exp(-2j * np.pi * 3 * np.arange(n) / n)) < 1e-13
