@@ -229,7 +229,9 @@ template <class T, class S, int F, bool SPLIT> constexpr size_t lds_bytes() {
     return (S::NP > 1) ? (size_t)F * S::pitch() * (SPLIT ? sizeof(T) : sizeof(cx<T>)) : 0;
 }
 
-template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, class X, class SRC, class DST>
+// SRC_IN_LDS: `src` reads the same LDS buffer the exchanges use (Rader/Bluestein second transform), so a
+// barrier separates the loads from the first scatter.
+template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, bool SRC_IN_LDS = false, class X, class SRC, class DST>
 MI_HD void wg_fft(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC src, DST dst) {
     static_assert(S::valid(), "radices must multiply to N");
     constexpr int R0 = S::R[0], NB0 = S::nb(0), BPT0 = S::bpt(0);
@@ -248,6 +250,7 @@ MI_HD void wg_fft(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC src, DS
             }
         });
     });
+    if constexpr (SRC_IN_LDS) ex.barrier();
     wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, 0>(ex, lds_raw, tw, src, dst);
 }
 

@@ -84,4 +84,101 @@ MI_HD void k2_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     wg_fft<T, S, F, MAP_FF, FIRST ? MAP_EF : MAP_FF, SPLIT>(ex, lds, p.tw, src, dst);
 }
 
+// ---- Bluestein: any length n <= (M + 1) / 2 through two length-M workgroup transforms ---------------------
+template <class T, class S, int F, class X>
+MI_HD void bluestein_body(X& ex, const BluesteinParams<T>& p, long long block, void* lds) {
+    constexpr int M = S::N, PITCH = S::pitch();
+    const long long fft0 = block * F;
+    const cx<T>* MI_RESTRICT in = p.in;
+    cx<T>* MI_RESTRICT out = p.out;
+    const cx<T>* MI_RESTRICT chirp = p.chirp;
+    const cx<T>* MI_RESTRICT bf = p.bf;
+    const long long batch = p.batch;
+    const int n = p.n;
+    const T sgn = p.sgn;
+    cx<T>* work = (cx<T>*)lds;  // natural-order spectrum; reuses the exchange buffer once the first transform is done
+    auto src1 = [=](int f, int i) -> cx<T> {
+        const long long g = fft0 + f;
+        if (g < batch && i < n) {
+            cx<T> x = in[g * n + i];
+            x.im *= sgn;
+            return x * chirp[i];
+        }
+        return cx<T>{0, 0};
+    };
+    auto dst1 = [=](int f, int j, cx<T> v) { work[f * PITCH + j] = cconj(v * bf[j]); };
+    wg_fft<T, S, F, MAP_EF, MAP_EF, false>(ex, lds, p.tw, src1, dst1);
+    ex.barrier();
+    auto src2 = [=](int f, int i) -> cx<T> { return work[f * PITCH + i]; };
+    auto dst2 = [=](int f, int j, cx<T> v) {
+        const long long g = fft0 + f;
+        if (g < batch && j < n) {
+            cx<T> y = cconj(v) * chirp[j];
+            y.im *= sgn;
+            out[g * n + j] = y;
+        }
+    };
+    wg_fft<T, S, F, MAP_EF, MAP_EF, false, true>(ex, lds, p.tw, src2, dst2);
+    (void)M;
+}
+
+// ---- Rader: prime length p = S::N + 1 ---------------------------------------------------------------------
+// LDS: [F][PITCH] exchange/work buffer followed by [F][p] staging of the rows (the g^j permutations are
+// random within a row, so they are applied against LDS, never against HBM).
+template <class T, class S, int F, class X>
+MI_HD void rader_body(X& ex, const RaderParams<T>& p, long long block, void* lds) {
+    constexpr int M = S::N, P = S::N + 1, PITCH = S::pitch(), NT = F * S::TPF;
+    const long long fft0 = block * F;
+    const cx<T>* MI_RESTRICT in = p.in;
+    cx<T>* MI_RESTRICT out = p.out;
+    const cx<T>* MI_RESTRICT dtab = p.d;
+    const int* MI_RESTRICT perm_in = p.perm_in;
+    const int* MI_RESTRICT perm_out = p.perm_out;
+    const long long batch = p.batch;
+    const T sgn = p.sgn;
+    cx<T>* work = (cx<T>*)lds;
+    cx<T>* rows = work + F * PITCH;
+    const long long rows_here = (batch - fft0) < F ? (batch - fft0) : F;
+    const int valid = (int)(rows_here * P);
+    // coalesced flat copy of this workgroup's rows into LDS
+    ex.for_threads([&](int tid, cx<T>*) {
+        for (int t = tid; t < F * P; t += NT) {
+            cx<T> x = cx<T>{0, 0};
+            if (t < valid) {
+                x = in[fft0 * P + t];
+                x.im *= sgn;
+            }
+            rows[t] = x;
+        }
+    });
+    ex.barrier();
+    auto src1 = [=](int f, int j) -> cx<T> { return rows[f * P + perm_in[j]]; };
+    auto dst1 = [=](int f, int j, cx<T> v) {
+        cx<T> t = cconj(v * dtab[j]);
+        if (j == 0) {
+            const cx<T> x0 = rows[f * P];
+            t = t + cconj(x0);
+            work[f * PITCH + M] = x0 + v;  // X[0]; slot M of the row is outside the transform's span (PITCH > M)
+        }
+        work[f * PITCH + j] = t;
+    };
+    wg_fft<T, S, F, MAP_EF, MAP_EF, false>(ex, lds, p.tw, src1, dst1);
+    ex.barrier();
+    // X[0] must leave `work` before the second transform's exchanges reuse the buffer
+    ex.for_threads([&](int tid, cx<T>*) {
+        if (tid < F) rows[tid * P] = work[tid * PITCH + M];
+    });
+    auto src2 = [=](int f, int i) -> cx<T> { return work[f * PITCH + i]; };
+    auto dst2 = [=](int f, int j, cx<T> v) { rows[f * P + perm_out[j]] = cconj(v); };
+    wg_fft<T, S, F, MAP_EF, MAP_EF, false, true>(ex, lds, p.tw, src2, dst2);
+    ex.barrier();
+    ex.for_threads([&](int tid, cx<T>*) {
+        for (int t = tid; t < valid; t += NT) {
+            cx<T> y = rows[t];
+            y.im *= sgn;
+            out[fft0 * P + t] = y;
+        }
+    });
+}
+
 }  // namespace mi355

@@ -28,4 +28,33 @@ template <class T> struct K2Params {
     T sgn_in, sgn_out;
 };
 
+// Bluestein (chirp-z) in one workgroup, src/algorithm/bluesteins_algorithm.rs:100-136:
+//   a[i] = x[i] * chirp[i] (zero padded to M);  A = FFT_M(a);  A[j] = conj(A[j] * bf[j]);
+//   A = FFT_M(A);  X[i] = conj(A[i]) * chirp[i]
+template <class T> struct BluesteinParams {
+    const cx<T>* in;
+    cx<T>* out;
+    const cx<T>* tw;     // sub-pass twiddles of the length-M transform
+    const cx<T>* chirp;  // n entries, w[i] = twiddle(i^2 mod 2n, 2n), forward (src/twiddles.rs:25-57)
+    const cx<T>* bf;     // M entries, FFT_M of the mirrored conjugate chirp / M (bluesteins_algorithm.rs:63-87)
+    long long batch;
+    int n;
+    T sgn;
+};
+
+// Rader in one workgroup, src/algorithm/raders_algorithm.rs:235-283 (p prime, inner length p - 1):
+//   s[j] = x[g^(j+1) mod p];  S = FFT(s);  X[0] = x[0] + S[0];  S[j] = conj(S[j] * d[j]);  S[0] += conj(x[0]);
+//   S = FFT(S);  X[g^-(j+1) mod p] = conj(S[j])
+template <class T> struct RaderParams {
+    const cx<T>* in;
+    cx<T>* out;
+    const cx<T>* tw;       // sub-pass twiddles of the length-(p-1) transform
+    const cx<T>* d;        // p-1 entries: FFT of twiddle(g^-j mod p, p) / (p-1)  (raders_algorithm.rs:87-113)
+    const int* perm_in;    // g^(j+1) mod p
+    const int* perm_out;   // g^-(j+1) mod p
+    long long batch;
+    int p;
+    T sgn;
+};
+
 }  // namespace mi355

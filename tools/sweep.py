@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Size sweep on one GPU: forward in-place transforms, HBM-resident, per-kernel HIP-event timings.
+Prints one JSON line per size: GFLOP/s (5 N log2 N), algorithmic GB/s per kernel and for the whole transform."""
+import argparse
+import json
+import math
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--min", type=int, default=10)
+    ap.add_argument("--max", type=int, default=24)
+    ap.add_argument("--bytes", type=float, default=2.0, help="buffer size in GiB")
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--chunk", type=int, default=0)
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+
+    import rustfft_amd
+
+    dt, tdt, esz = (np.complex64, torch.complex64, 8) if args.dtype == "f32" else (np.complex128, torch.complex128, 16)
+    planner = rustfft_amd.FftPlanner(dt)
+    for p in range(args.min, args.max + 1):
+        n = 1 << p
+        batch = max(1, int(args.bytes * 2**30) // (n * esz))
+        x = torch.empty(batch * n, dtype=tdt, device="cuda")
+        torch.view_as_real(x).uniform_(-1.0, 1.0)
+        fft = planner.plan_fft_forward(n)
+        fft.set_chunk_batch(args.chunk)
+        fft.process(x)
+        torch.cuda.synchronize()
+        torch.view_as_real(x).uniform_(-1.0, 1.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.reps):
+            fft.process(x)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.reps
+        torch.view_as_real(x).uniform_(-1.0, 1.0)
+        kms = fft.profile_kernels(x, reps=args.reps)
+        alg = batch * 2 * n * esz
+        print(json.dumps({"log2n": p, "batch": batch, "ms": round(ms, 4), "gflops": round(batch * 5.0 * n * p / ms / 1e6, 1),
+                          "alg_GBps": round(alg / ms / 1e6, 1), "kernel_ms": [round(k, 4) for k in kms],
+                          "kernel_GBps": [round(alg / k / 1e6, 1) for k in kms], "plan": fft.describe()}), flush=True)
+        del x
+
+
+if __name__ == "__main__":
+    main()
