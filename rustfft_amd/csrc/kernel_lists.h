@@ -19,3 +19,17 @@
     MI_K1(T, PREC, 2, false, 2048, 128, 16, 16, 8);   \
     MI_K1(T, PREC, 1, false, 4096, 256, 16, 16, 16)
 
+
+// Bluestein bodies, one per inner power-of-two length M (serves every n with 2n - 1 <= M)
+#define MI_BS_LIST(T, PREC)                        \
+    MI_BS(T, PREC, 64, 8, 2, 4, 2);                \
+    MI_BS(T, PREC, 64, 16, 4, 4, 4);               \
+    MI_BS(T, PREC, 64, 32, 4, 8, 4);               \
+    MI_BS(T, PREC, 32, 64, 8, 8, 8);               \
+    MI_BS(T, PREC, 32, 128, 8, 16, 8);             \
+    MI_BS(T, PREC, 16, 256, 16, 16, 16);           \
+    MI_BS(T, PREC, 8, 512, 32, 16, 8, 4);          \
+    MI_BS(T, PREC, 4, 1024, 64, 16, 16, 4);        \
+    MI_BS(T, PREC, 2, 2048, 128, 16, 16, 8);       \
+    MI_BS(T, PREC, 1, 4096, 256, 16, 16, 16);      \
+    MI_BS(T, PREC, 1, 8192, 512, 16, 8, 8, 8)

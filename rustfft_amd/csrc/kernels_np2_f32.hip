@@ -1,0 +1,11 @@
+// Non-power-of-two instantiations, Complex<float>: native mixed radix for BASELINE config 3 (N = 1200),
+// Rader for config 4 (N = 1009, inner 1008 = 16 x 9 x 7) and the Bluestein bodies that cover every other length.
+#include "launch.h"
+#include "kernel_lists.h"
+namespace mi355 {
+void register_np2_f32(std::vector<KernelEntry>& reg) {
+    MI_K1(float, 32, 2, false, 1200, 120, 10, 10, 12);
+    MI_RADER(float, 32, 2, 1008, 144, 16, 9, 7);
+    MI_BS_LIST(float, 32);
+}
+}  // namespace mi355

@@ -74,6 +74,64 @@ template <class T, class S, int F, bool FIRST, bool SPLIT> KernelEntry make_k2(i
     };
     return e;
 }
+template <class T, class S, int F>
+__global__ __launch_bounds__(F* S::TPF) void bluestein_kernel(BluesteinParams<T> p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevExec<T, regs_needed<S, false>()> ex;
+    bluestein_body<T, S, F>(ex, p, (long long)blockIdx.x, smem);
+}
+template <class T, class S, int F>
+__global__ __launch_bounds__(F* S::TPF) void rader_kernel(RaderParams<T> p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevExec<T, regs_needed<S, false>()> ex;
+    rader_body<T, S, F>(ex, p, (long long)blockIdx.x, smem);
+}
+template <class T, class S, int F> constexpr size_t bluestein_lds() { return (size_t)F * S::pitch() * sizeof(cx<T>); }
+template <class T, class S, int F> constexpr size_t rader_lds() { return (size_t)F * (S::pitch() + S::N + 1) * sizeof(cx<T>); }
+
+template <class T, class S, int F> KernelEntry make_bluestein(int prec, const char* name) {
+    KernelEntry e{};
+    e.kind = KIND_BLUESTEIN;
+    e.prec = prec;
+    e.n = S::N;
+    e.f = F;
+    fill_sched<S>(e);
+    e.threads = F * S::TPF;
+    e.lds_bytes = bluestein_lds<T, S, F>();
+    e.name = name;
+    e.launch = [](const void* params, long long grid, void* stream) {
+        void* args[] = {const_cast<void*>(params)};
+        (void)hipLaunchKernel((const void*)bluestein_kernel<T, S, F>, dim3((unsigned)grid), dim3(F * S::TPF), args,
+                              bluestein_lds<T, S, F>(), (hipStream_t)stream);
+    };
+    e.prepare = []() -> int {
+        return (int)hipFuncSetAttribute((const void*)bluestein_kernel<T, S, F>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)bluestein_lds<T, S, F>());
+    };
+    return e;
+}
+template <class T, class S, int F> KernelEntry make_rader(int prec, const char* name) {
+    KernelEntry e{};
+    e.kind = KIND_RADER;
+    e.prec = prec;
+    e.n = S::N;
+    e.aux = S::N + 1;
+    e.f = F;
+    fill_sched<S>(e);
+    e.threads = F * S::TPF;
+    e.lds_bytes = rader_lds<T, S, F>();
+    e.name = name;
+    e.launch = [](const void* params, long long grid, void* stream) {
+        void* args[] = {const_cast<void*>(params)};
+        (void)hipLaunchKernel((const void*)rader_kernel<T, S, F>, dim3((unsigned)grid), dim3(F * S::TPF), args,
+                              rader_lds<T, S, F>(), (hipStream_t)stream);
+    };
+    e.prepare = []() -> int {
+        return (int)hipFuncSetAttribute((const void*)rader_kernel<T, S, F>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)rader_lds<T, S, F>());
+    };
+    return e;
+}
 #else
 // -------------------------------------------------------------------------------- host emulator
 template <class T, int NREG> struct HostExec {
@@ -127,11 +185,57 @@ template <class T, class S, int F, bool FIRST, bool SPLIT> KernelEntry make_k2(i
     e.prepare = []() -> int { return 0; };
     return e;
 }
+template <class T, class S, int F> constexpr size_t bluestein_lds() { return (size_t)F * S::pitch() * sizeof(cx<T>); }
+template <class T, class S, int F> constexpr size_t rader_lds() { return (size_t)F * (S::pitch() + S::N + 1) * sizeof(cx<T>); }
+template <class T, class S, int F> KernelEntry make_bluestein(int prec, const char* name) {
+    KernelEntry e{};
+    e.kind = KIND_BLUESTEIN;
+    e.prec = prec;
+    e.n = S::N;
+    e.f = F;
+    fill_sched<S>(e);
+    e.threads = F * S::TPF;
+    e.lds_bytes = bluestein_lds<T, S, F>();
+    e.name = name;
+    e.launch = [](const void* params, long long grid, void*) {
+        std::vector<char> lds(bluestein_lds<T, S, F>() + 64, (char)0x5a);
+        for (long long b = 0; b < grid; ++b) {
+            HostExec<T, regs_needed<S, false>()> ex(F * S::TPF);
+            bluestein_body<T, S, F>(ex, *(const BluesteinParams<T>*)params, b, lds.data());
+        }
+    };
+    e.prepare = []() -> int { return 0; };
+    return e;
+}
+template <class T, class S, int F> KernelEntry make_rader(int prec, const char* name) {
+    KernelEntry e{};
+    e.kind = KIND_RADER;
+    e.prec = prec;
+    e.n = S::N;
+    e.aux = S::N + 1;
+    e.f = F;
+    fill_sched<S>(e);
+    e.threads = F * S::TPF;
+    e.lds_bytes = rader_lds<T, S, F>();
+    e.name = name;
+    e.launch = [](const void* params, long long grid, void*) {
+        std::vector<char> lds(rader_lds<T, S, F>() + 64, (char)0x5a);
+        for (long long b = 0; b < grid; ++b) {
+            HostExec<T, regs_needed<S, false>()> ex(F * S::TPF);
+            rader_body<T, S, F>(ex, *(const RaderParams<T>*)params, b, lds.data());
+        }
+    };
+    e.prepare = []() -> int { return 0; };
+    return e;
+}
 #endif
 
 #define MI_K1(T, PREC, F, SPLIT, ...) reg.push_back(make_k1<T, Sched<__VA_ARGS__>, F, SPLIT>(PREC, "k1<" #__VA_ARGS__ ">xF" #F))
 #define MI_K2(T, PREC, F, SPLIT, ...)                                                                  \
     reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, true, SPLIT>(PREC, "k2first<" #__VA_ARGS__ ">xF" #F)); \
     reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, false, SPLIT>(PREC, "k2later<" #__VA_ARGS__ ">xF" #F))
+
+#define MI_BS(T, PREC, F, ...) reg.push_back(make_bluestein<T, Sched<__VA_ARGS__>, F>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F))
+#define MI_RADER(T, PREC, F, ...) reg.push_back(make_rader<T, Sched<__VA_ARGS__>, F>(PREC, "rader<" #__VA_ARGS__ ">xF" #F))
 
 }  // namespace mi355

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <complex>
 #include <cstring>
 #include <mutex>
 #include <sstream>
@@ -30,6 +31,8 @@ void ensure_registry() {
         register_k1_f64(r);
         register_k2_f32(r);
         register_k2_f64(r);
+        register_np2_f32(r);
+        register_np2_f64(r);
     });
 }
 
@@ -85,6 +88,100 @@ template <class T> static void* upload(Plan& plan, const std::vector<T>& host, i
         }
     }
     return d;
+}
+
+// ---- host-side double precision DFT used only to precompute the Rader / Bluestein spectra -------------------
+typedef std::complex<double> cd;
+static void host_dft(std::vector<cd>& a) {
+    const size_t n = a.size();
+    if (n <= 1) return;
+    std::vector<cd> w(n);
+    for (size_t i = 0; i < n; ++i) {
+        double re, im;
+        twiddle_f64(i, n, &re, &im);
+        w[i] = cd(re, im);
+    }
+    if ((n & (n - 1)) == 0) {  // iterative radix-2, twiddles from the exact table
+        for (size_t i = 1, j = 0; i < n; ++i) {
+            size_t bit = n >> 1;
+            for (; j & bit; bit >>= 1) j ^= bit;
+            j ^= bit;
+            if (i < j) std::swap(a[i], a[j]);
+        }
+        for (size_t len = 2; len <= n; len <<= 1) {
+            const size_t step = n / len;
+            for (size_t i = 0; i < n; i += len)
+                for (size_t k = 0; k < len / 2; ++k) {
+                    cd u = a[i + k], v = a[i + k + len / 2] * w[k * step];
+                    a[i + k] = u + v;
+                    a[i + k + len / 2] = u - v;
+                }
+        }
+        return;
+    }
+    std::vector<cd> out(n);
+    for (size_t k = 0; k < n; ++k) {
+        cd acc(0, 0);
+        size_t idx = 0;
+        for (size_t j = 0; j < n; ++j) {
+            acc += a[j] * w[idx];
+            idx += k;
+            if (idx >= n) idx -= n;
+        }
+        out[k] = acc;
+    }
+    a.swap(out);
+}
+template <class T> static std::vector<T> to_interleaved(const std::vector<cd>& v) {
+    std::vector<T> o;
+    o.reserve(v.size() * 2);
+    for (auto& c : v) {
+        o.push_back((T)c.real());
+        o.push_back((T)c.imag());
+    }
+    return o;
+}
+// src/twiddles.rs:25-57 — chirp w[i] = twiddle(i^2 mod 2n, 2n), forward
+static std::vector<cd> bluestein_chirp(size_t n) {
+    std::vector<cd> w(n);
+    for (size_t i = 0; i < n; ++i) {
+        unsigned __int128 sq = (unsigned __int128)i * i;
+        size_t e = (size_t)(sq % (unsigned __int128)(2 * n));
+        double re, im;
+        twiddle_f64(e, 2 * n, &re, &im);
+        w[i] = cd(re, im);
+    }
+    return w;
+}
+static uint64_t modpow(uint64_t b, uint64_t e, uint64_t m) {
+    unsigned __int128 r = 1, bb = b % m;
+    while (e) {
+        if (e & 1) r = r * bb % m;
+        bb = bb * bb % m;
+        e >>= 1;
+    }
+    return (uint64_t)r;
+}
+// smallest primitive root of the prime p (same definition as src/math_utils.rs:3-20)
+static uint64_t primitive_root(uint64_t p) {
+    std::vector<uint64_t> fs;
+    uint64_t m = p - 1;
+    for (uint64_t d = 2; d * d <= m; ++d)
+        if (m % d == 0) {
+            fs.push_back(d);
+            while (m % d == 0) m /= d;
+        }
+    if (m > 1) fs.push_back(m);
+    for (uint64_t g = 2; g < p; ++g) {
+        bool ok = true;
+        for (uint64_t f : fs)
+            if (modpow(g, (p - 1) / f, p) == 1) {
+                ok = false;
+                break;
+            }
+        if (ok) return g;
+    }
+    return 0;
 }
 
 // choose macro radices r_1..r_P (each with a FIRST and a LATER kernel) whose product is n:
@@ -178,6 +275,68 @@ template <class T> static int build_plan_t(Plan& plan) {
         }
         return MI355FFT_OK;
     }
+    // prime length with a compiled Rader body (raders_algorithm.rs:65-124 precomputation, in f64)
+    for (auto& e : registry()) {
+        if (e.kind != KIND_RADER || e.prec != plan.prec || (size_t)e.aux != n) continue;
+        if (e.prepare()) return MI355FFT_ERR_HIP;
+        const uint64_t pp = n, g = primitive_root(pp), ginv = modpow(g, pp - 2, pp);
+        std::vector<cd> d(pp - 1);
+        std::vector<int> pin(pp - 1), pout(pp - 1);
+        uint64_t ti = 1, a = 1, b = 1;
+        for (size_t j = 0; j + 1 < pp; ++j) {
+            double re, im;
+            twiddle_f64(ti, pp, &re, &im);
+            d[j] = cd(re, im) / (double)(pp - 1);
+            ti = ti * ginv % pp;
+            a = a * g % pp;
+            b = b * ginv % pp;
+            pin[j] = (int)a;
+            pout[j] = (int)b;
+        }
+        host_dft(d);
+        plan.kind = PLAN_RADER;
+        PassDesc pd{};
+        pd.k = &e;
+        pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(e), &rc);
+        if (rc) return rc;
+        pd.d_aux1 = upload<T>(plan, to_interleaved<T>(d), &rc);
+        if (rc) return rc;
+        pd.d_perm_in = upload<int>(plan, pin, &rc);
+        if (rc) return rc;
+        pd.d_perm_out = upload<int>(plan, pout, &rc);
+        if (rc) return rc;
+        plan.passes.push_back(pd);
+        return MI355FFT_OK;
+    }
+    // any other length that fits one workgroup: Bluestein over the smallest compiled M >= 2n - 1
+    {
+        const KernelEntry* best = nullptr;
+        for (auto& e : registry())
+            if (e.kind == KIND_BLUESTEIN && e.prec == plan.prec && (size_t)e.n >= 2 * n - 1 && (!best || e.n < best->n)) best = &e;
+        if (best) {
+            if (best->prepare()) return MI355FFT_ERR_HIP;
+            const size_t M = best->n;
+            std::vector<cd> chirp = bluestein_chirp(n), bvec(M, cd(0, 0));
+            // bluesteins_algorithm.rs:63-87: mirrored conjugate chirp scaled by 1/M, then the forward FFT_M
+            bvec[0] = std::conj(chirp[0]) / (double)M;
+            for (size_t i = 1; i < n; ++i) {
+                bvec[i] = std::conj(chirp[i]) / (double)M;
+                bvec[M - i] = bvec[i];
+            }
+            host_dft(bvec);
+            plan.kind = PLAN_BLUESTEIN;
+            PassDesc pd{};
+            pd.k = best;
+            pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(*best), &rc);
+            if (rc) return rc;
+            pd.d_aux1 = upload<T>(plan, to_interleaved<T>(chirp), &rc);
+            if (rc) return rc;
+            pd.d_aux2 = upload<T>(plan, to_interleaved<T>(bvec), &rc);
+            if (rc) return rc;
+            plan.passes.push_back(pd);
+            return MI355FFT_OK;
+        }
+    }
     return MI355FFT_ERR_UNSUPPORTED;
 }
 
@@ -222,6 +381,31 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         p.out = (cx<T>*)out;
         p.tw = (const cx<T>*)pd.d_tw;
         p.batch = (long long)batch;
+        p.sgn = inverse ? (T)-1 : (T)1;
+        grid = (long long)((batch + k.f - 1) / k.f);
+        k.launch(&p, grid, stream);
+    } else if (k.kind == KIND_BLUESTEIN) {
+        BluesteinParams<T> p{};
+        p.in = (const cx<T>*)in;
+        p.out = (cx<T>*)out;
+        p.tw = (const cx<T>*)pd.d_tw;
+        p.chirp = (const cx<T>*)pd.d_aux1;
+        p.bf = (const cx<T>*)pd.d_aux2;
+        p.batch = (long long)batch;
+        p.n = (int)plan.len;
+        p.sgn = inverse ? (T)-1 : (T)1;
+        grid = (long long)((batch + k.f - 1) / k.f);
+        k.launch(&p, grid, stream);
+    } else if (k.kind == KIND_RADER) {
+        RaderParams<T> p{};
+        p.in = (const cx<T>*)in;
+        p.out = (cx<T>*)out;
+        p.tw = (const cx<T>*)pd.d_tw;
+        p.d = (const cx<T>*)pd.d_aux1;
+        p.perm_in = (const int*)pd.d_perm_in;
+        p.perm_out = (const int*)pd.d_perm_out;
+        p.batch = (long long)batch;
+        p.p = (int)plan.len;
         p.sgn = inverse ? (T)-1 : (T)1;
         grid = (long long)((batch + k.f - 1) / k.f);
         k.launch(&p, grid, stream);

@@ -10,7 +10,7 @@
 
 namespace mi355 {
 
-enum PlanKind { PLAN_TRIVIAL = 0, PLAN_SINGLE = 1, PLAN_MACRO = 2 };
+enum PlanKind { PLAN_TRIVIAL = 0, PLAN_SINGLE = 1, PLAN_MACRO = 2, PLAN_BLUESTEIN = 3, PLAN_RADER = 4 };
 
 struct PassDesc {
     const KernelEntry* k;
@@ -19,6 +19,10 @@ struct PassDesc {
     void* d_thi;
     int hshift, lmask;
     long long m, s;  // M = N / R and S = product of the earlier macro radices
+    void* d_aux1;  // Bluestein: chirp[n]        Rader: d[p-1]
+    void* d_aux2;  // Bluestein: bf[M]
+    void* d_perm_in;   // Rader: g^(j+1) mod p
+    void* d_perm_out;  // Rader: g^-(j+1) mod p
 };
 
 struct Workspace {

@@ -33,6 +33,8 @@ void register_k1_f32(std::vector<KernelEntry>&);
 void register_k1_f64(std::vector<KernelEntry>&);
 void register_k2_f32(std::vector<KernelEntry>&);
 void register_k2_f64(std::vector<KernelEntry>&);
+void register_np2_f32(std::vector<KernelEntry>&);  // non-power-of-two: mixed radix, Rader, Bluestein
+void register_np2_f64(std::vector<KernelEntry>&);
 
 template <class S> inline void fill_sched(KernelEntry& e) {
     e.tpf = S::TPF;

@@ -191,3 +191,93 @@ def test_concurrent_process_on_one_plan(planners, oracle):
         want = inputs[t].copy()
         ref.process(want)
         assert compare_vectors(want, results[t])
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+@pytest.mark.parametrize("direction", [0, 1])
+def test_accuracy_1_to_1000(planners, oracle, dtype, direction):
+    """tests/accuracy.rs:128-187 on the GPU: planner output for every length 1..1000 vs the reference's control
+    (BluesteinsAlgorithm over Radix4, tests/accuracy.rs:98-122) through the in-place, out-of-place and
+    immutable entry points (tests/accuracy.rs:39-82), tolerance tests/accuracy.rs:30-37."""
+    planner = planners[np.dtype(dtype)]
+    for n in range(1, 1001):
+        inner_len = 1
+        while inner_len < 2 * n - 1:
+            inner_len *= 2
+        control = oracle.bluesteins(n, oracle.radix4(dtype, inner_len, direction))
+        fft = planner.plan_fft(n, direction)
+        assert fft.len() == n and int(fft.fft_direction()) == direction
+        x = random_signal(n, dtype)
+        ctrl = x.copy()
+        control.process_with_scratch(ctrl, np.zeros(control.get_inplace_scratch_len(), dtype=dtype))
+        a = x.copy()
+        fft.process_with_scratch(a, np.zeros(fft.get_inplace_scratch_len(), dtype=dtype))
+        i2, b = x.copy(), x.copy()
+        fft.process_outofplace_with_scratch(i2, b, np.zeros(0, dtype=dtype))
+        c = x.copy()
+        fft.process_immutable_with_scratch(x, c, np.zeros(0, dtype=dtype))
+        assert compare_vectors(ctrl, a) and compare_vectors(ctrl, b) and compare_vectors(ctrl, c), n
+
+
+def test_config3_n1200_f64(planners, oracle):
+    """BASELINE config 3: N = 1200 Complex<f64>, batch 65536 on HBM-resident data; all four API modes on a
+    3-row slice (mirrors check_fft_algorithm) and 64 sampled rows of the full batch vs the oracle's
+    RadixN{[5,5,2], Butterfly24} recipe."""
+    import torch
+
+    n, batch = 1200, 65536
+    planner = planners[np.dtype(np.complex128)]
+    fft = planner.plan_fft_forward(n)
+    assert "k1<1200" in fft.describe()
+    check_fft_algorithm(fft, n, 0, reference=oracle.plan(np.complex128, n, 0))
+    check_fft_algorithm(planner.plan_fft_inverse(n), n, 1, reference=oracle.plan(np.complex128, n, 1))
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x52555354 + 3)
+    x = torch.empty(batch * n, dtype=torch.complex128, device="cuda")
+    torch.view_as_real(x).uniform_(0.0, 10.0, generator=g)
+    y = x.clone()
+    fft.process(y)
+    torch.cuda.synchronize()
+    ref = oracle.plan(np.complex128, n, 0)
+    rows = np.random.default_rng(3).choice(batch, 64, replace=False)
+    for r in rows:
+        xr = x[r * n:(r + 1) * n].cpu().numpy()
+        want = xr.copy()
+        ref.process(want)
+        got = y[r * n:(r + 1) * n].cpu().numpy()
+        assert compare_vectors(want, got) and rel_l2(got, want) < 1e-13, r
+    planner.plan_fft_inverse(n).process(y)
+    assert ((y / n - x).abs().max().item()) < 1e-10
+
+
+@pytest.mark.parametrize("n,tag", [(1009, "rader<1008"), (1019, "bluestein<2048")])
+def test_config4_prime_sizes_f32(planners, oracle, n, tag):
+    """BASELINE config 4: N = 1009 (Rader; the reference plans RadersAlgorithm over RadixN{[7,6],B24}) and the
+    complementary Bluestein prime 1019, Complex<f32>, batch 2^20 on HBM-resident data; 64 sampled rows vs the
+    oracle, plus the round trip on all rows."""
+    import torch
+
+    batch = 1 << 20
+    planner = planners[np.dtype(np.complex64)]
+    fft = planner.plan_fft_forward(n)
+    assert tag in fft.describe()
+    check_fft_algorithm(fft, n, 0, reference=oracle.plan(np.complex64, n, 0), n=5)
+    check_fft_algorithm(planner.plan_fft_inverse(n), n, 1, reference=oracle.plan(np.complex64, n, 1), n=5)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x52555354 + 4)
+    x = torch.empty(batch * n, dtype=torch.complex64, device="cuda")
+    torch.view_as_real(x).uniform_(0.0, 10.0, generator=g)
+    y = x.clone()
+    fft.process(y)
+    torch.cuda.synchronize()
+    ref = oracle.plan(np.complex64, n, 0)
+    rows = np.random.default_rng(4).choice(batch, 64, replace=False)
+    for r in rows:
+        xr = x[r * n:(r + 1) * n].cpu().numpy()
+        want = xr.copy()
+        ref.process(want)
+        got = y[r * n:(r + 1) * n].cpu().numpy()
+        assert compare_vectors(want, got), r
+        assert rel_l2(got, numpy_fft(xr, n, False)) < REL[np.dtype(np.complex64)], r
+    planner.plan_fft_inverse(n).process(y)
+    assert (y / n - x).abs().mean().item() < 1e-4

@@ -127,3 +127,45 @@ def test_linearity_and_shift(emu_planner):
     imp[3] = 1.0
     fft.process(imp)
     assert rel_l2(imp, np.exp(-2j * np.pi * 3 * np.arange(n) / n)) < 1e-13
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+@pytest.mark.parametrize("direction", [0, 1])
+def test_accuracy_1_to_1000(emu_planner, oracle, dtype, direction):
+    """tests/accuracy.rs:128-187 restated against the kernel bodies: every length 1..1000 (Bluestein bodies for
+    the non-powers of two, Rader for 1009-class primes, native mixed radix where compiled) vs the reference's
+    control = BluesteinsAlgorithm over Radix4 (tests/accuracy.rs:98-122), via the three API paths."""
+    planner = emu_planner(dtype)
+    for n in range(1, 1001):
+        inner_len = 1
+        while inner_len < 2 * n - 1:
+            inner_len *= 2
+        control = oracle.bluesteins(n, oracle.radix4(dtype, inner_len, direction))
+        fft = planner.plan_fft(n, direction)
+        assert fft.len() == n and int(fft.fft_direction()) == direction
+        x = random_signal(n, dtype)
+        ctrl = x.copy()
+        control.process_with_scratch(ctrl, np.zeros(control.get_inplace_scratch_len(), dtype=dtype))
+        a = x.copy()
+        fft.process_with_scratch(a, np.zeros(fft.get_inplace_scratch_len(), dtype=dtype))
+        i2, b = x.copy(), x.copy()
+        fft.process_outofplace_with_scratch(i2, b, np.zeros(0, dtype=dtype))
+        c = x.copy()
+        fft.process_immutable_with_scratch(x, c, np.zeros(0, dtype=dtype))
+        assert compare_vectors(ctrl, a) and compare_vectors(ctrl, b) and compare_vectors(ctrl, c), n
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_baseline_configs_3_and_4(emu_planner, oracle, dtype):
+    """Config 3: N = 1200 (native mixed radix 10 x 10 x 12); config 4: N = 1009 (Rader over 16 x 9 x 7) and its
+    Bluestein companion 1019 (M = 2048): all four API modes, ragged batch (tail workgroup partially filled)."""
+    planner = emu_planner(dtype)
+    for n, tag in ((1200, "k1<1200"), (1009, "rader<1008"), (1019, "bluestein<2048"), (719, "bluestein<2048")):
+        for d in (0, 1):
+            fft = planner.plan_fft(n, d)
+            assert tag in fft.describe(), fft.describe()
+            check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=5)
+            x = zero_mean_signal(n * 3, dtype)
+            y = x.copy()
+            fft.process(y)
+            assert rel_l2(y, numpy_fft(x, n, d == 1)) < (2e-6 if dtype == np.complex64 else 1e-13)
