@@ -14,6 +14,14 @@
 #define MI_RESTRICT __restrict__
 #endif
 
+// Scheduling fence between independent butterflies of one thread: keeps the compiler from interleaving them
+// (which doubles the live temporaries and spills in the 32-values-per-thread tiles).  No-op on the host.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MI_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define MI_SCHED_FENCE() ((void)0)
+#endif
+
 namespace mi355 {
 
 template <class T> struct cx {

@@ -99,6 +99,7 @@ template <class T, class S, int P> MI_HD void compute_pass(cx<T>* v, int u, cons
             }
             butterfly<R>(v + m * R);
         }
+        if constexpr (BPT > 1 && R * BPT > 16) MI_SCHED_FENCE();
     });
 }
 
@@ -191,13 +192,13 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
             });
             ex.barrier();
         } else {
-            // real plane out, imaginary plane in flight: the new real parts land in a side array so the
-            // old imaginary parts (still needed for the second scatter) are not overwritten
+            // real plane first, then the imaginary plane, through the same half-size buffer.  The two planes
+            // live in different registers, so the new real parts can land in v[].re while v[].im still holds the
+            // old layout's imaginary parts: no side array is needed.
             ex.for_threads([&](int tid, cx<T>* v) {
                 int f, u;
                 map_tid<MQ, F, S::TPF>(tid, f, u);
-                cx<T>* side = v + S::emax();
-                lds_gather<T, S, P + 1, 1>(side, u, (const T*)lds_raw + f * S::pitch());
+                lds_gather<T, S, P + 1, 1>(v, u, (const T*)lds_raw + f * S::pitch());
             });
             ex.barrier();
             ex.for_threads([&](int tid, cx<T>* v) {
@@ -209,12 +210,7 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
             ex.for_threads([&](int tid, cx<T>* v) {
                 int f, u;
                 map_tid<MQ, F, S::TPF>(tid, f, u);
-                cx<T>* side = v + S::emax();
-                lds_gather<T, S, P + 1, 2>(side, u, (const T*)lds_raw + f * S::pitch());
-                static_for<0, S::emax()>([&](auto I_) {
-                    constexpr int i = I_;
-                    v[i] = side[i];
-                });
+                lds_gather<T, S, P + 1, 2>(v, u, (const T*)lds_raw + f * S::pitch());
             });
             ex.barrier();
         }
@@ -222,8 +218,22 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
     }
 }
 
+// Source adaptor: element-wise functor -> the per-butterfly interface the first sub-pass uses.
+// A source may instead implement bfly<R>() itself to share work across the R inputs of a butterfly
+// (the inter-pass twiddle recurrence of the large-N passes does).
+template <class L> struct ElemSrc {
+    L load;
+    template <int R, class T> MI_HD void bfly(int f, int b, int nb, cx<T>* v) const {
+        static_for<0, R>([&](auto K_) {
+            constexpr int k = K_;
+            v[k] = load(f, b + k * nb);
+        });
+    }
+};
+template <class L> MI_HD ElemSrc<L> elem_src(L l) { return ElemSrc<L>{l}; }
+
 // register array length an executor must provide per thread
-template <class S, bool SPLIT> constexpr int regs_needed() { return SPLIT ? 2 * S::emax() : S::emax(); }
+template <class S, bool SPLIT> constexpr int regs_needed() { return S::emax(); }
 // LDS bytes one workgroup needs
 template <class T, class S, int F, bool SPLIT> constexpr size_t lds_bytes() {
     return (S::NP > 1) ? (size_t)F * S::pitch() * (SPLIT ? sizeof(T) : sizeof(cx<T>)) : 0;
@@ -243,11 +253,9 @@ MI_HD void wg_fft(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC src, DS
             constexpr int m = M_;
             const int b = u + m * S::TPF;
             if ((m + 1) * S::TPF <= NB0 || b < NB0) {
-                static_for<0, R0>([&](auto K_) {
-                    constexpr int k = K_;
-                    v[m * R0 + k] = src(f, b + k * NB0);
-                });
+                src.template bfly<R0>(f, b, NB0, v + m * R0);
             }
+            if constexpr (BPT0 > 1 && R0 * BPT0 > 16) MI_SCHED_FENCE();
         });
     });
     if constexpr (SRC_IN_LDS) ex.barrier();

@@ -23,32 +23,88 @@ namespace mi355 {
 template <class T, class S, int F, bool SPLIT, class X>
 MI_HD void k1_body(X& ex, const K1Params<T>& p, long long block, void* lds) {
     const long long fft0 = block * F;
-    const cx<T>* MI_RESTRICT in = p.in;
-    cx<T>* MI_RESTRICT out = p.out;
-    const long long batch = p.batch;
+    // workgroup-uniform base + 32-bit element offsets (F * N < 2^31): one address VGPR per access
+    const cx<T>* MI_RESTRICT in = p.in + fft0 * S::N;
+    cx<T>* MI_RESTRICT out = p.out + fft0 * S::N;
+    const int rows = (int)((p.batch - fft0) < F ? (p.batch - fft0) : F);
     const T sgn = p.sgn;
     auto src = [=](int f, int i) -> cx<T> {
-        const long long g = fft0 + f;
-        if (g < batch) {
-            cx<T> x = in[g * S::N + i];
+        if (f < rows) {
+            cx<T> x = in[(unsigned)(f * S::N + i)];
             x.im *= sgn;
             return x;
         }
         return cx<T>{0, 0};
     };
     auto dst = [=](int f, int i, cx<T> x) {
-        const long long g = fft0 + f;
-        if (g < batch) {
+        if (f < rows) {
             x.im *= sgn;
-            out[g * S::N + i] = x;
+            out[(unsigned)(f * S::N + i)] = x;
         }
     };
-    wg_fft<T, S, F, MAP_EF, MAP_EF, SPLIT>(ex, lds, p.tw, src, dst);
+    wg_fft<T, S, F, MAP_EF, MAP_EF, SPLIT>(ex, lds, p.tw, elem_src(src), dst);
 }
+
+// Source of a large-N pass: F-element row segments, times the inter-pass twiddle w_Q^{c j} (Q = S R,
+// c = B mod S, j = row).  A thread's butterfly needs rows j = b + k nb, k = 0..R-1, so
+//     w^{c j} = w^{c b} * (w^{c nb})^k :
+// two two-level table look-ups (base and step) per butterfly, then step^(2^i) by squaring and each power
+// through at most log2(R) multiplications.  This replaces 2 R divergent table gathers per butterfly.
+template <class T, bool FIRST> struct K2Src {
+    const cx<T>* MI_RESTRICT in;
+    long long M, b0, bmod0;
+    T sgn_in;
+    const cx<T>* MI_RESTRICT tlo;
+    const cx<T>* MI_RESTRICT thi;
+    int hshift, lmask, dbg;
+    MI_HD cx<T> lut(unsigned e) const { return tlo[e & (unsigned)lmask] * thi[e >> hshift]; }
+    // K: index reached so far, J0: lowest bit position still allowed to be added
+    template <int R, int LOG, int K, int J0> MI_HD static void apply_tw(cx<T>* v, cx<T> w, const cx<T>* sp) {
+        v[K] = v[K] * w;
+        static_for<J0, LOG>([&](auto J_) {
+            constexpr int j = J_;
+            if constexpr (K + (1 << j) < R) apply_tw<R, LOG, K + (1 << j), j + 1>(v, w * sp[j], sp);
+        });
+    }
+    template <int R, class TT> MI_HD void bfly(int f, int b, int nb, cx<TT>* v) const {
+        // 32-bit element offsets from the (workgroup-uniform) transform base: one VGPR per address instead of two
+        const unsigned col = (unsigned)(b0 + f), m32 = (unsigned)M;
+        static_for<0, R>([&](auto K_) {
+            constexpr int k = K_;
+            cx<T> x = in[col + (unsigned)(b + k * nb) * m32];
+            x.im *= sgn_in;
+            v[k] = x;
+        });
+        if constexpr (!FIRST) {
+            if (dbg & 1) return;  // measurement knob: skip the twiddles (wrong results)
+            const unsigned c = (unsigned)(bmod0 + f);
+            constexpr int LOG = (R > 16) ? 5 : (R > 8) ? 4 : (R > 4) ? 3 : (R > 2) ? 2 : (R > 1) ? 1 : 0;
+            cx<T> sp[LOG > 0 ? LOG : 1];
+            if constexpr (LOG > 0) {
+                sp[0] = lut(c * (unsigned)nb);
+                static_for<1, LOG>([&](auto I_) {
+                    constexpr int i = I_;
+                    sp[i] = sp[i - 1] * sp[i - 1];
+                });
+            }
+            // depth-first walk over the bits of k: w_{k + 2^j} = w_k * step^(2^j).  At most log2(R)+1 twiddles are
+            // live at a time (a flat table of R of them is what pushed the 32-values-per-thread tiles into spills).
+            apply_tw<R, LOG, 0, 0>(v, lut(c * (unsigned)b), sp);
+        }
+    }
+};
 
 template <class T, class S, int F, bool FIRST, bool SPLIT, class X>
 MI_HD void k2_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     constexpr int R = S::N;
+    // XCD-aware tile order.  Workgroup b is dispatched to XCD b % 8 (MI355X_MICROARCH.md, observed, used
+    // for speed only).  When a tile's row segment is narrower than the 128-byte L2 line (pair = 128 /
+    // (F * sizeof(C)) > 1), the `pair` tiles sharing each line are given to the same XCD back to back, so the
+    // line is fetched into one L2 once instead of into several L2s.
+    if (p.pair > 1) {
+        const long long grp = 8LL * p.pair;
+        block = (block / grp) * grp + (block % 8) * p.pair + (block / 8) % p.pair;
+    }
     const long long g = block / p.tiles_per_fft;
     const long long tile = block % p.tiles_per_fft;
     const long long b0 = tile * F;
@@ -62,22 +118,14 @@ MI_HD void k2_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     // a tile never straddles a multiple of S (F | S whenever S > 1), so B div S is tile-uniform
     const long long bdiv = FIRST ? 0 : (b0 / Sg);
     const long long bmod0 = FIRST ? 0 : (b0 % Sg);
-    auto src = [=](int f, int j) -> cx<T> {
-        cx<T> x = in[b0 + f + (long long)j * M];
-        x.im *= sgn_in;
-        if constexpr (!FIRST) {
-            const unsigned e = (unsigned)(bmod0 + f) * (unsigned)j;
-            const cx<T> w = tlo[e & lmask] * thi[e >> hshift];
-            x = x * w;
-        }
-        return x;
-    };
+    const unsigned obase = (unsigned)(bdiv * Sg * R + bmod0), s32 = (unsigned)Sg;
+    K2Src<T, FIRST> src{in, M, b0, bmod0, sgn_in, tlo, thi, hshift, lmask, p.dbg};
     auto dst = [=](int f, int k, cx<T> x) {
         x.im *= sgn_out;
         if constexpr (FIRST)
-            out[(b0 + f) * R + k] = x;
+            out[(unsigned)(b0 + f) * (unsigned)R + (unsigned)k] = x;
         else
-            out[bdiv * Sg * R + bmod0 + f + (long long)k * Sg] = x;
+            out[obase + (unsigned)f + (unsigned)k * s32] = x;
     };
     // first pass: lanes walk across the tile's columns on the way in and along each sequence on the way
     // out (the F*R output block is contiguous); later passes: across columns both ways
@@ -107,7 +155,7 @@ MI_HD void bluestein_body(X& ex, const BluesteinParams<T>& p, long long block, v
         return cx<T>{0, 0};
     };
     auto dst1 = [=](int f, int j, cx<T> v) { work[f * PITCH + j] = cconj(v * bf[j]); };
-    wg_fft<T, S, F, MAP_EF, MAP_EF, false>(ex, lds, p.tw, src1, dst1);
+    wg_fft<T, S, F, MAP_EF, MAP_EF, false>(ex, lds, p.tw, elem_src(src1), dst1);
     ex.barrier();
     auto src2 = [=](int f, int i) -> cx<T> { return work[f * PITCH + i]; };
     auto dst2 = [=](int f, int j, cx<T> v) {
@@ -118,7 +166,7 @@ MI_HD void bluestein_body(X& ex, const BluesteinParams<T>& p, long long block, v
             out[g * n + j] = y;
         }
     };
-    wg_fft<T, S, F, MAP_EF, MAP_EF, false, true>(ex, lds, p.tw, src2, dst2);
+    wg_fft<T, S, F, MAP_EF, MAP_EF, false, true>(ex, lds, p.tw, elem_src(src2), dst2);
     (void)M;
 }
 
@@ -162,7 +210,7 @@ MI_HD void rader_body(X& ex, const RaderParams<T>& p, long long block, void* lds
         }
         work[f * PITCH + j] = t;
     };
-    wg_fft<T, S, F, MAP_EF, MAP_EF, false>(ex, lds, p.tw, src1, dst1);
+    wg_fft<T, S, F, MAP_EF, MAP_EF, false>(ex, lds, p.tw, elem_src(src1), dst1);
     ex.barrier();
     // X[0] must leave `work` before the second transform's exchanges reuse the buffer
     ex.for_threads([&](int tid, cx<T>*) {
@@ -170,7 +218,7 @@ MI_HD void rader_body(X& ex, const RaderParams<T>& p, long long block, void* lds
     });
     auto src2 = [=](int f, int i) -> cx<T> { return work[f * PITCH + i]; };
     auto dst2 = [=](int f, int j, cx<T> v) { rows[f * P + perm_out[j]] = cconj(v); };
-    wg_fft<T, S, F, MAP_EF, MAP_EF, false, true>(ex, lds, p.tw, src2, dst2);
+    wg_fft<T, S, F, MAP_EF, MAP_EF, false, true>(ex, lds, p.tw, elem_src(src2), dst2);
     ex.barrier();
     ex.for_threads([&](int tid, cx<T>*) {
         for (int t = tid; t < valid; t += NT) {

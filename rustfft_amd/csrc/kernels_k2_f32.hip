@@ -7,6 +7,11 @@ void register_k2_f32(std::vector<KernelEntry>& reg) {
     MI_K2(float, 32, 64, false, 128, 8, 16, 8);
     MI_K2(float, 32, 32, false, 256, 16, 16, 16);
     MI_K2(float, 32, 16, false, 512, 32, 16, 8, 4);
-    MI_K2(float, 32, 16, true, 1024, 32, 16, 16, 4);
+    // 1024-row tile: 16 columns (128-byte row segments), 32 values per thread, real/imaginary planes exchanged
+    // one after the other so two workgroups fit a CU's LDS; the twiddled sub-passes are radix 8 (fewer live twiddles)
+    MI_K2(float, 32, 16, true, 1024, 32, 8, 8, 16);
+    MI_K2V(1, float, 32, 8, false, 1024, 64, 16, 16, 4);   // tuning: 64-byte row segments paired per XCD, full-complex exchange
+    MI_K2V(2, float, 32, 16, true, 1024, 32, 16, 8, 8);    // tuning: radix-16 first sub-pass
+    MI_K2V(3, float, 32, 16, false, 1024, 64, 16, 16, 4);  // tuning: 1024 threads, one workgroup per CU
 }
 }  // namespace mi355

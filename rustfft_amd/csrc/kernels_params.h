@@ -26,6 +26,8 @@ template <class T> struct K2Params {
     long long batch;          // number of length-N transforms
     long long tiles_per_fft;  // M / F
     T sgn_in, sgn_out;
+    int pair;  // tiles per 128-byte line (XCD-aware ordering), 1 = identity
+    int dbg;   // measurement knobs (bit 0: skip the inter-pass twiddles); 0 in production
 };
 
 // Bluestein (chirp-z) in one workgroup, src/algorithm/bluesteins_algorithm.rs:100-136:

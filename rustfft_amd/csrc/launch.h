@@ -23,8 +23,10 @@ __global__ __launch_bounds__(F* S::TPF) void k1_kernel(K1Params<T> p) {
     DevExec<T, regs_needed<S, SPLIT>()> ex;
     k1_body<T, S, F, SPLIT>(ex, p, (long long)blockIdx.x, smem);
 }
+// two workgroups per CU is what keeps HBM busy while the other workgroup computes: ask the register
+// allocator for (2 * threads / 256) waves per SIMD
 template <class T, class S, int F, bool FIRST, bool SPLIT>
-__global__ __launch_bounds__(F* S::TPF) void k2_kernel(K2Params<T> p) {
+__global__ __launch_bounds__(F* S::TPF, (F * S::TPF >= 512 ? 4 : 2)) void k2_kernel(K2Params<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevExec<T, regs_needed<S, SPLIT>()> ex;
     k2_body<T, S, F, FIRST, SPLIT>(ex, p, (long long)blockIdx.x, smem);
@@ -231,6 +233,11 @@ template <class T, class S, int F> KernelEntry make_rader(int prec, const char* 
 #endif
 
 #define MI_K1(T, PREC, F, SPLIT, ...) reg.push_back(make_k1<T, Sched<__VA_ARGS__>, F, SPLIT>(PREC, "k1<" #__VA_ARGS__ ">xF" #F))
+#define MI_K2V(V, T, PREC, F, SPLIT, ...)                                                                   \
+    reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, true, SPLIT>(PREC, "k2first<" #__VA_ARGS__ ">xF" #F "v" #V));  \
+    reg.back().variant = V;                                                                                  \
+    reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, false, SPLIT>(PREC, "k2later<" #__VA_ARGS__ ">xF" #F "v" #V)); \
+    reg.back().variant = V
 #define MI_K2(T, PREC, F, SPLIT, ...)                                                                  \
     reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, true, SPLIT>(PREC, "k2first<" #__VA_ARGS__ ">xF" #F)); \
     reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, false, SPLIT>(PREC, "k2later<" #__VA_ARGS__ ">xF" #F))

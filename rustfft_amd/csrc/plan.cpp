@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <complex>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <sstream>
@@ -36,10 +37,20 @@ void ensure_registry() {
     });
 }
 
+static int env_int(const char* name) {
+    const char* s = getenv(name);
+    return s ? atoi(s) : 0;
+}
+// default tiling = variant 0; MI355FFT_VARIANT=v prefers a variant-v instantiation where one exists (tuning aid)
 static const KernelEntry* find_kernel(int kind, int prec, size_t n) {
+    const int want = env_int("MI355FFT_VARIANT");
+    const KernelEntry* fallback = nullptr;
     for (auto& e : registry())
-        if (e.kind == kind && e.prec == prec && (size_t)e.n == n) return &e;
-    return nullptr;
+        if (e.kind == kind && e.prec == prec && (size_t)e.n == n) {
+            if (e.variant == want) return &e;
+            if (e.variant == 0) fallback = &e;
+        }
+    return fallback;
 }
 
 // src/twiddles.rs:6-23 — forward twiddle, f64 angle, rounded to T by the caller
@@ -189,7 +200,9 @@ static uint64_t primitive_root(uint64_t p) {
 static bool choose_macro_radices(int prec, size_t n, std::vector<size_t>& out) {
     std::vector<size_t> avail;
     for (auto& e : registry())
-        if (e.kind == KIND_K2_FIRST && e.prec == prec && find_kernel(KIND_K2_LATER, prec, e.n)) avail.push_back(e.n);
+        if (e.kind == KIND_K2_FIRST && e.prec == prec && e.variant == 0 && find_kernel(KIND_K2_LATER, prec, e.n) &&
+            (env_int("MI355FFT_MAXR") == 0 || e.n <= env_int("MI355FFT_MAXR")))
+            avail.push_back(e.n);
     std::sort(avail.begin(), avail.end(), std::greater<size_t>());
     avail.erase(std::unique(avail.begin(), avail.end()), avail.end());
     std::vector<size_t> best, cur;
@@ -239,7 +252,8 @@ template <class T> static int build_plan_t(Plan& plan) {
         return MI355FFT_OK;
     }
     std::vector<size_t> radices;
-    if (choose_macro_radices(plan.prec, n, radices)) {
+    // the large-N passes address one transform with 32-bit element offsets
+    if (n < ((size_t)1 << 31) && choose_macro_radices(plan.prec, n, radices)) {
         plan.kind = PLAN_MACRO;
         size_t s = 1;
         for (size_t p = 0; p < radices.size(); ++p) {
@@ -425,6 +439,13 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         p.tiles_per_fft = pd.m / k.f;
         p.sgn_in = (inverse && pi == 0) ? (T)-1 : (T)1;
         p.sgn_out = (inverse && pi + 1 == plan.passes.size()) ? (T)-1 : (T)1;
+        p.dbg = env_int("MI355FFT_DBG");
+        {
+            const long long seg = (long long)k.f * (long long)(2 * sizeof(T));
+            long long pair = seg < 128 ? 128 / seg : 1;
+            if ((p.tiles_per_fft * (long long)batch) % (8 * pair) != 0 || (env_int("MI355FFT_DBG") & 2)) pair = 1;
+            p.pair = (int)pair;
+        }
         grid = (long long)batch * p.tiles_per_fft;
         k.launch(&p, grid, stream);
     }

@@ -19,7 +19,8 @@ struct KernelEntry {
     size_t lds_bytes;
     int tw_total;  // entries in the sub-pass twiddle table
     bool split;
-    int aux;  // kind-specific (Rader/Bluestein: inner length)
+    int aux;      // kind-specific (Rader: the prime p)
+    int variant;  // 0 = default; other values are alternative tilings selectable with MI355FFT_VARIANT (tuning)
     const char* name;
     void (*launch)(const void* params, long long grid, void* stream);
     int (*prepare)();  // one-time setup (dynamic-LDS attribute); returns 0 on success

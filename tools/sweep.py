@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--sizes", default="", help="comma-separated explicit lengths (overrides --min/--max)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -26,8 +27,9 @@ def main():
 
     dt, tdt, esz = (np.complex64, torch.complex64, 8) if args.dtype == "f32" else (np.complex128, torch.complex128, 16)
     planner = rustfft_amd.FftPlanner(dt)
-    for p in range(args.min, args.max + 1):
-        n = 1 << p
+    sizes = [int(v) for v in args.sizes.split(",")] if args.sizes else [1 << q for q in range(args.min, args.max + 1)]
+    for n in sizes:
+        p = math.log2(n)
         batch = max(1, int(args.bytes * 2**30) // (n * esz))
         x = torch.empty(batch * n, dtype=tdt, device="cuda")
         torch.view_as_real(x).uniform_(-1.0, 1.0)
@@ -46,7 +48,7 @@ def main():
         torch.view_as_real(x).uniform_(-1.0, 1.0)
         kms = fft.profile_kernels(x, reps=args.reps)
         alg = batch * 2 * n * esz
-        print(json.dumps({"log2n": p, "batch": batch, "ms": round(ms, 4), "gflops": round(batch * 5.0 * n * p / ms / 1e6, 1),
+        print(json.dumps({"n": n, "log2n": round(p, 3), "batch": batch, "ms": round(ms, 4), "gflops": round(batch * 5.0 * n * p / ms / 1e6, 1),
                           "alg_GBps": round(alg / ms / 1e6, 1), "kernel_ms": [round(k, 4) for k in kms],
                           "kernel_GBps": [round(alg / k / 1e6, 1) for k in kms], "plan": fft.describe()}), flush=True)
         del x
