@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="transforms per GPU")
     ap.add_argument("--chunk", type=int, default=-1, help="transforms per workspace chunk (-1 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
     args = ap.parse_args()
 
     import numpy as np
@@ -117,10 +118,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from rustfft_amd.sharding import reduce_max
+
+    elapsed = reduce_max(elapsed, dist, device="cuda")  # MAX over ranks (RCCL all-reduce of one scalar)
     finite = bool(torch.isfinite(torch.view_as_real(data[: 1 << 16])).all().item())
 
     flops_per_step = world * 2 * batch * 5.0 * n * math.log2(n)
@@ -147,8 +147,23 @@ def main():
         dom = max(per_kernel, key=lambda r: r["ms"])
         out["roofline"] = {"bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": dom["GBps"] / HBM_PEAK_GBS, "traffic": None, "kernel": dom["kernel"],
+                           "algorithmic_bytes_per_launch": alg_bytes,
                            "kernels": per_kernel,
                            "transform_algorithmic_frac": (batch * 2 * n * 8) / (sum(r["ms"] for r in per_kernel) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if world == 1 and not args.no_pmc:
+            # HBM bytes per launch of the dominant kernel from PMC counters (two extra short rocprofv3 runs)
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import pmc_traffic
+
+                pmc = pmc_traffic.collect(["--steps", "1", "--warmup", "1", "--log2n", str(args.log2n), "--batch", str(batch)])
+                for rk, rv in pmc.items():
+                    if pmc_traffic.rocprof_name_matches(dom["kernel"], rk):
+                        out["roofline"]["traffic"] = rv["traffic_bytes"]
+                        out["roofline"]["traffic_detail"] = {"fetch_bytes_x2_corrected": rv["fetch_bytes"], "write_bytes": rv["write_bytes"],
+                                                             "algorithmic_bytes": alg_bytes, "unit": "bytes per launch"}
+            except Exception as e:
+                log(f"pmc traffic unavailable: {e}")
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(n, log)
