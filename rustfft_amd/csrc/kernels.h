@@ -170,6 +170,28 @@ MI_HD void bluestein_body(X& ex, const BluesteinParams<T>& p, long long block, v
     (void)M;
 }
 
+// ---- element-wise stages of the multi-kernel Bluestein (one thread per output element, grid-stride) ---------
+template <class T> MI_HD void pointwise_elem(const PointwiseParams<T>& p, long long idx) {
+    if (p.stage == 0) {
+        const long long r = idx / p.m, i = idx % p.m;
+        cx<T> v{0, 0};
+        if (i < p.n) {
+            v = p.in[r * p.n + i];
+            v.im *= p.sgn;
+            v = v * p.tab[i];
+        }
+        p.out[idx] = v;
+    } else if (p.stage == 1) {
+        const long long j = idx % p.m;
+        p.out[idx] = cconj(p.in[idx] * p.tab[j]);
+    } else {
+        const long long r = idx / p.n, i = idx % p.n;
+        cx<T> v = cconj(p.in[r * p.m + i]) * p.tab[i];
+        v.im *= p.sgn;
+        p.out[idx] = v;
+    }
+}
+
 // ---- Rader: prime length p = S::N + 1 ---------------------------------------------------------------------
 // LDS: [F][PITCH] exchange/work buffer followed by [F][p] staging of the rows (the g^j permutations are
 // random within a row, so they are applied against LDS, never against HBM).

@@ -7,5 +7,6 @@ void register_np2_f32(std::vector<KernelEntry>& reg) {
     MI_K1(float, 32, 2, false, 1200, 120, 10, 10, 12);
     MI_RADER(float, 32, 2, 1008, 144, 16, 9, 7);
     MI_BS_LIST(float, 32);
+    reg.push_back(make_pointwise<float>(32));
 }
 }  // namespace mi355

@@ -7,5 +7,6 @@ void register_np2_f64(std::vector<KernelEntry>& reg) {
     MI_K1(double, 64, 2, false, 1200, 120, 10, 10, 12);
     MI_RADER(double, 64, 2, 1008, 144, 16, 9, 7);
     MI_BS_LIST(double, 64);
+    reg.push_back(make_pointwise<double>(64));
 }
 }  // namespace mi355

@@ -59,4 +59,20 @@ template <class T> struct RaderParams {
     T sgn;
 };
 
+// Element-wise stages of the multi-kernel Bluestein used for lengths that do not fit one workgroup
+// (same algebra as BluesteinParams; the two length-M transforms are ordinary power-of-two plans):
+//   stage 0: w[r][i] = (i < n) ? x[r][i] * chirp[i] : 0          (zero-pad to M)
+//   stage 1: w[r][j] = conj(w[r][j] * bf[j])
+//   stage 2: y[r][i] = conj(w[r][i]) * chirp[i],  i < n
+template <class T> struct PointwiseParams {
+    const cx<T>* in;
+    cx<T>* out;
+    const cx<T>* tab;   // chirp (stages 0, 2) or bf (stage 1)
+    long long rows;
+    long long n;        // outer length
+    long long m;        // inner (padded) length
+    int stage;
+    T sgn;              // conj-in (stage 0) / conj-out (stage 2) for the inverse direction
+};
+
 }  // namespace mi355

@@ -88,6 +88,24 @@ __global__ __launch_bounds__(F* S::TPF) void rader_kernel(RaderParams<T> p) {
     DevExec<T, regs_needed<S, false>()> ex;
     rader_body<T, S, F>(ex, p, (long long)blockIdx.x, smem);
 }
+template <class T> __global__ __launch_bounds__(256) void pointwise_kernel(PointwiseParams<T> p, long long total) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) pointwise_elem<T>(p, i);
+}
+template <class T> KernelEntry make_pointwise(int prec) {
+    KernelEntry e{};
+    e.kind = KIND_POINTWISE;
+    e.prec = prec;
+    e.threads = 256;
+    e.name = "bluestein_pointwise";
+    e.launch = [](const void* params, long long total, void* stream) {
+        long long blocks = (total + 255) / 256;
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        void* args[] = {const_cast<void*>(params), &total};
+        (void)hipLaunchKernel((const void*)pointwise_kernel<T>, dim3((unsigned)blocks), dim3(256), args, 0, (hipStream_t)stream);
+    };
+    e.prepare = []() -> int { return 0; };
+    return e;
+}
 template <class T, class S, int F> constexpr size_t bluestein_lds() { return (size_t)F * S::pitch() * sizeof(cx<T>); }
 template <class T, class S, int F> constexpr size_t rader_lds() { return (size_t)F * (S::pitch() + S::N + 1) * sizeof(cx<T>); }
 
@@ -183,6 +201,18 @@ template <class T, class S, int F, bool FIRST, bool SPLIT> KernelEntry make_k2(i
             HostExec<T, regs_needed<S, SPLIT>()> ex(F * S::TPF);
             k2_body<T, S, F, FIRST, SPLIT>(ex, *(const K2Params<T>*)params, b, lds.data());
         }
+    };
+    e.prepare = []() -> int { return 0; };
+    return e;
+}
+template <class T> KernelEntry make_pointwise(int prec) {
+    KernelEntry e{};
+    e.kind = KIND_POINTWISE;
+    e.prec = prec;
+    e.threads = 256;
+    e.name = "bluestein_pointwise";
+    e.launch = [](const void* params, long long total, void*) {
+        for (long long i = 0; i < total; ++i) pointwise_elem<T>(*(const PointwiseParams<T>*)params, i);
     };
     e.prepare = []() -> int { return 0; };
     return e;

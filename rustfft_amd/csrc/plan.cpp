@@ -351,6 +351,39 @@ template <class T> static int build_plan_t(Plan& plan) {
             return MI355FFT_OK;
         }
     }
+    // any other length: multi-kernel Bluestein over a power-of-two plan of length M >= 2n - 1
+    // (bluesteins_algorithm.rs:58-136 with the inner FFT_M realised by the K1 / K2 kernels)
+    {
+        size_t M = 1;
+        while (M < 2 * n - 1) M <<= 1;
+        const KernelEntry* pw = nullptr;
+        for (auto& e : registry())
+            if (e.kind == KIND_POINTWISE && e.prec == plan.prec) pw = &e;
+        if (pw && M < ((size_t)1 << 31)) {
+            plan.inner.reset(new Plan());
+            plan.inner->len = M;
+            plan.inner->direction = MI355FFT_FORWARD;
+            plan.inner->prec = plan.prec;
+            int irc = build_plan_t<T>(*plan.inner);
+            if (irc) return irc;
+            std::vector<cd> chirp = bluestein_chirp(n), bvec(M, cd(0, 0));
+            bvec[0] = std::conj(chirp[0]) / (double)M;
+            for (size_t i = 1; i < n; ++i) {
+                bvec[i] = std::conj(chirp[i]) / (double)M;
+                bvec[M - i] = bvec[i];
+            }
+            host_dft(bvec);
+            plan.kind = PLAN_BLUESTEIN_LARGE;
+            PassDesc pd{};
+            pd.k = pw;
+            pd.d_aux1 = upload<T>(plan, to_interleaved<T>(chirp), &rc);
+            if (rc) return rc;
+            pd.d_aux2 = upload<T>(plan, to_interleaved<T>(bvec), &rc);
+            if (rc) return rc;
+            plan.passes.push_back(pd);
+            return MI355FFT_OK;
+        }
+    }
     return MI355FFT_ERR_UNSUPPORTED;
 }
 
@@ -362,6 +395,10 @@ int build_plan(Plan& plan) {
 std::string Plan::describe() const {
     std::ostringstream s;
     if (kind == PLAN_TRIVIAL) s << "trivial(len=" << len << ")";
+    if (kind == PLAN_BLUESTEIN_LARGE) {
+        s << "bluestein_large(M=" << inner->len << ": " << inner->describe() << ")";
+        return s.str();
+    }
     for (size_t i = 0; i < passes.size(); ++i) s << (i ? " -> " : "") << passes[i].k->name;
     return s.str();
 }
@@ -460,6 +497,42 @@ template <class T> static int execute_t(Plan& plan, const void* in, void* out, s
     if (batch == 0 || n == 0) return MI355FFT_OK;
     if (plan.kind == PLAN_TRIVIAL) {  // len 1: the DFT is the identity (reference plans Dft(1), src/plan.rs:313-314)
         if (in != out && backend::d2d(out, in, batch * n * esz, stream)) return MI355FFT_ERR_HIP;
+        return MI355FFT_OK;
+    }
+    if (plan.kind == PLAN_BLUESTEIN_LARGE) {
+        const size_t M = plan.inner->len;
+        const PassDesc& pd = plan.passes[0];
+        const bool inverse = plan.direction == MI355FFT_INVERSE;
+        size_t chunk = std::max<size_t>(1, ((size_t)1 << 29) / (M * esz));  // <= 512 MiB of padded rows at a time
+        if (chunk > batch) chunk = batch;
+        char* ws = (char*)plan.workspace_for(stream, chunk * M * esz);
+        if (!ws) return MI355FFT_ERR_OUT_OF_MEMORY;
+        for (size_t c0 = 0; c0 < batch; c0 += chunk) {
+            const size_t rows = std::min(chunk, batch - c0);
+            PointwiseParams<T> pp{};
+            pp.rows = (long long)rows;
+            pp.n = (long long)n;
+            pp.m = (long long)M;
+            pp.sgn = inverse ? (T)-1 : (T)1;
+            pp.in = (const cx<T>*)((const char*)in + c0 * n * esz);
+            pp.out = (cx<T>*)ws;
+            pp.tab = (const cx<T>*)pd.d_aux1;
+            pp.stage = 0;
+            pd.k->launch(&pp, (long long)(rows * M), stream);
+            int rc = execute_t<T>(*plan.inner, ws, ws, rows, stream, 0, nullptr);
+            if (rc) return rc;
+            pp.in = (const cx<T>*)ws;
+            pp.tab = (const cx<T>*)pd.d_aux2;
+            pp.stage = 1;
+            pd.k->launch(&pp, (long long)(rows * M), stream);
+            rc = execute_t<T>(*plan.inner, ws, ws, rows, stream, 0, nullptr);
+            if (rc) return rc;
+            pp.out = (cx<T>*)((char*)out + c0 * n * esz);
+            pp.tab = (const cx<T>*)pd.d_aux1;
+            pp.stage = 2;
+            pd.k->launch(&pp, (long long)(rows * n), stream);
+            if (backend::check_launch()) return MI355FFT_ERR_HIP;
+        }
         return MI355FFT_OK;
     }
     const size_t P = plan.passes.size();

@@ -1,6 +1,7 @@
 // Plan object behind `mi355fft_plan` (include/mi355fft.h).
 #pragma once
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -10,7 +11,7 @@
 
 namespace mi355 {
 
-enum PlanKind { PLAN_TRIVIAL = 0, PLAN_SINGLE = 1, PLAN_MACRO = 2, PLAN_BLUESTEIN = 3, PLAN_RADER = 4 };
+enum PlanKind { PLAN_TRIVIAL = 0, PLAN_SINGLE = 1, PLAN_MACRO = 2, PLAN_BLUESTEIN = 3, PLAN_RADER = 4, PLAN_BLUESTEIN_LARGE = 5 };
 
 struct PassDesc {
     const KernelEntry* k;
@@ -48,6 +49,7 @@ struct Plan {
     std::map<void*, Workspace> workspaces;  // one HBM workspace per stream
     std::mutex host_mutex;                  // serialises the host-slice staging path
     Workspace stage_a, stage_b;
+    std::unique_ptr<Plan> inner;  // PLAN_BLUESTEIN_LARGE: forward power-of-two plan of the padded length M
 
     ~Plan();
     std::string describe() const;

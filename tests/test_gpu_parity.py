@@ -166,7 +166,7 @@ def test_error_paths(planners):
     with pytest.raises(rustfft_amd.FftPanic, match="must be a multiple of FFT length"):
         f.process(torch.zeros(300, dtype=torch.complex64, device="cuda"))
     with pytest.raises(rustfft_amd.FftPanic, match="no GPU plan"):
-        planners[np.dtype(np.complex64)].plan_fft_forward(3 * 1000003)
+        planners[np.dtype(np.complex64)].plan_fft_forward((1 << 30) + 1)  # would need a 2^31-point inner transform
 
 
 def test_concurrent_process_on_one_plan(planners, oracle):
@@ -281,3 +281,18 @@ def test_config4_prime_sizes_f32(planners, oracle, n, tag):
         assert rel_l2(got, numpy_fft(xr, n, False)) < REL[np.dtype(np.complex64)], r
     planner.plan_fft_inverse(n).process(y)
     assert (y / n - x).abs().mean().item() < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_lengths_beyond_one_workgroup(planners, oracle, dtype):
+    """Non-powers of two above 4096 (multi-kernel Bluestein): primes the reference plans as Rader / Bluestein, a
+    smooth composite (RadixN on the CPU), a product of two large primes (MixedRadix on the CPU)."""
+    planner = planners[np.dtype(dtype)]
+    for n in (4097, 5000, 5759, 10007, 101 * 103, 100003, 3 * (1 << 15)):
+        for d in (0, 1):
+            fft = planner.plan_fft(n, d)
+            check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=2)
+            x = zero_mean_signal(n * 2, dtype)
+            y = x.copy()
+            fft.process(y)
+            assert rel_l2(y, numpy_fft(x, n, d == 1)) < REL[np.dtype(dtype)], (n, d)

@@ -110,7 +110,7 @@ def test_unsupported_length_fails_loudly(emu_planner):
     import rustfft_amd
 
     with pytest.raises(rustfft_amd.FftPanic, match="no GPU plan"):
-        emu_planner(np.complex64).plan_fft_forward(3 * 1000003)
+        emu_planner(np.complex64).plan_fft_forward((1 << 30) + 1)  # would need a 2^31-point inner transform
 
 
 def test_linearity_and_shift(emu_planner):
@@ -169,3 +169,16 @@ def test_baseline_configs_3_and_4(emu_planner, oracle, dtype):
             y = x.copy()
             fft.process(y)
             assert rel_l2(y, numpy_fft(x, n, d == 1)) < (2e-6 if dtype == np.complex64 else 1e-13)
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_lengths_beyond_one_workgroup(emu_planner, oracle, dtype):
+    """Non-powers of two above 4096 (multi-kernel Bluestein over the large-N passes): a prime the reference plans
+    as Rader (10007), a 'difficult' prime it plans as Bluestein (2879 * 2 + ... -> 5759), a smooth composite (5000 -> RadixN)
+    and a product of two large primes (101 * 103 -> MixedRadix), all four API modes."""
+    planner = emu_planner(dtype)
+    for n in (4097, 5000, 5759, 10007, 101 * 103):
+        for d in (0, 1):
+            fft = planner.plan_fft(n, d)
+            assert "bluestein_large" in fft.describe()
+            check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=2)
