@@ -48,9 +48,24 @@ template <int N_, int TPF_, int... Rs> struct Sched {
         return o;
     }
     static constexpr int tw_total() { return tw_offset(NP); }
-    // LDS padding: one extra slot every PADDIV elements makes the stride-R_0 scatter of the first
-    // exchange conflict-free (bank math: MI355X_MICROARCH.md §LDS)
-    static constexpr int paddiv() { return (NP > 1 && R[0] % 2 == 0) ? R[0] : 0; }
+    // ---- LDS layout of exchange x (written by sub-pass x, read by sub-pass x+1) ----------------------------
+    // Power-of-two schedules use an XOR swizzle: sub-pass x scatters runs of s_x consecutive elements at stride
+    // s_x R_x; XOR-ing the run index (scaled by s_x) into the bank bits puts the runs of one wave on distinct
+    // banks, while any 32-aligned block of consecutive elements (what the gather side reads) only sees a
+    // constant XOR, i.e. stays conflict-free (bank math: MI355X_MICROARCH.md §LDS).  Other schedules fall back to
+    // one padding slot every R_0 elements.
+    static constexpr bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+    static constexpr bool all_pow2() {
+        for (int p = 0; p < NP; ++p)
+            if (!is_pow2(R[p])) return false;
+        return N >= 32;
+    }
+    static constexpr int ilog2(int v) {
+        int l = 0;
+        while ((1 << (l + 1)) <= v) ++l;
+        return l;
+    }
+    static constexpr int paddiv() { return (!all_pow2() && NP > 1 && R[0] % 2 == 0) ? R[0] : 0; }
     static constexpr int phys(int i) {
         constexpr int d = paddiv();
         if constexpr (d != 0)
@@ -58,7 +73,14 @@ template <int N_, int TPF_, int... Rs> struct Sched {
         else
             return i;
     }
-    static constexpr int pitch() { return (phys(N - 1) + 1) | 1; }  // odd pitch: MAP_FF lanes hit distinct banks
+    // pitch between sequences: PITCH_MOD32 = 1 (odd) suits lanes that walk across >= 32 sequences; the column-tile
+    // kernels with F < 32 ask for 32 / F so that the (32 / F) slots of one lane group land on the remaining banks
+    template <int PITCH_MOD32> static constexpr int pitch_for() {
+        int p = phys(N - 1) + 1;
+        while ((p % 32) != (PITCH_MOD32 % 32)) ++p;
+        return p;
+    }
+    static constexpr int pitch() { return pitch_for<1>(); }
     static constexpr bool valid() {
         int prod = 1;
         for (int p = 0; p < NP; ++p) prod *= R[p];
@@ -66,11 +88,18 @@ template <int N_, int TPF_, int... Rs> struct Sched {
     }
 };
 
-template <class S> MI_HD int lds_phys(int i) {
-    if constexpr (S::paddiv() != 0)
+template <class S, int X> MI_HD int lds_phys(int i) {
+    if constexpr (S::all_pow2()) {
+        constexpr int ST = S::stride(X), SR = S::stride(X) * S::R[X];
+        if constexpr (ST < 32)
+            return i ^ (((i >> S::ilog2(SR)) << S::ilog2(ST)) & 31);
+        else
+            return i;
+    } else if constexpr (S::paddiv() != 0) {
         return i + i / S::paddiv();
-    else
+    } else {
         return i;
+    }
 }
 
 template <Map M, int F, int TPF> MI_HD void map_tid(int tid, int& f, int& u) {
@@ -114,7 +143,7 @@ template <class T, class S, int P, int PART, class E> MI_HD void lds_scatter(con
             const int base = (b / ST) * (ST * R) + (b % ST);
             static_for<0, R>([&](auto K_) {
                 constexpr int k = K_;
-                const int o = lds_phys<S>(base + k * ST);
+                const int o = lds_phys<S, P>(base + k * ST);
                 if constexpr (PART == 0)
                     ldsf[o] = v[m * R + k];
                 else if constexpr (PART == 1)
@@ -133,7 +162,7 @@ template <class T, class S, int P, int PART, class E> MI_HD void lds_gather(cx<T
         if ((m + 1) * S::TPF <= NB || b < NB) {
             static_for<0, R>([&](auto K_) {
                 constexpr int k = K_;
-                const int o = lds_phys<S>(b + k * NB);
+                const int o = lds_phys<S, P - 1>(b + k * NB);
                 if constexpr (PART == 0)
                     v[m * R + k] = ldsf[o];
                 else if constexpr (PART == 1)
@@ -153,7 +182,7 @@ template <class S, int P, Map MIN, Map MOUT> constexpr Map pass_map() {
 // X: executor. X::for_threads(fn(tid, cx<T>* v)) runs fn for every thread of the workgroup with that
 //    thread's private register array; X::barrier() is the workgroup barrier.
 // src(f, i) -> cx<T>: input element i of sequence f;   dst(f, i, value): output element i.
-template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, int P, class X, class SRC, class DST>
+template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, int PM, int P, class X, class SRC, class DST>
 MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& src, DST& dst) {
     constexpr int R = S::R[P], NB = S::nb(P), ST = S::stride(P), BPT = S::bpt(P);
     constexpr Map MP = pass_map<S, P, MIN, MOUT>();
@@ -176,9 +205,9 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
                 }
             });
         } else if constexpr (!SPLIT) {
-            lds_scatter<T, S, P, 0>(v, u, (cx<T>*)lds_raw + f * S::pitch());
+            lds_scatter<T, S, P, 0>(v, u, (cx<T>*)lds_raw + f * S::template pitch_for<PM>());
         } else {
-            lds_scatter<T, S, P, 1>(v, u, (T*)lds_raw + f * S::pitch());
+            lds_scatter<T, S, P, 1>(v, u, (T*)lds_raw + f * S::template pitch_for<PM>());
         }
     });
     if constexpr (!LAST) {
@@ -188,7 +217,7 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
             ex.for_threads([&](int tid, cx<T>* v) {
                 int f, u;
                 map_tid<MQ, F, S::TPF>(tid, f, u);
-                lds_gather<T, S, P + 1, 0>(v, u, (const cx<T>*)lds_raw + f * S::pitch());
+                lds_gather<T, S, P + 1, 0>(v, u, (const cx<T>*)lds_raw + f * S::template pitch_for<PM>());
             });
             ex.barrier();
         } else {
@@ -198,23 +227,23 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
             ex.for_threads([&](int tid, cx<T>* v) {
                 int f, u;
                 map_tid<MQ, F, S::TPF>(tid, f, u);
-                lds_gather<T, S, P + 1, 1>(v, u, (const T*)lds_raw + f * S::pitch());
+                lds_gather<T, S, P + 1, 1>(v, u, (const T*)lds_raw + f * S::template pitch_for<PM>());
             });
             ex.barrier();
             ex.for_threads([&](int tid, cx<T>* v) {
                 int f, u;
                 map_tid<MP, F, S::TPF>(tid, f, u);
-                lds_scatter<T, S, P, 2>(v, u, (T*)lds_raw + f * S::pitch());
+                lds_scatter<T, S, P, 2>(v, u, (T*)lds_raw + f * S::template pitch_for<PM>());
             });
             ex.barrier();
             ex.for_threads([&](int tid, cx<T>* v) {
                 int f, u;
                 map_tid<MQ, F, S::TPF>(tid, f, u);
-                lds_gather<T, S, P + 1, 2>(v, u, (const T*)lds_raw + f * S::pitch());
+                lds_gather<T, S, P + 1, 2>(v, u, (const T*)lds_raw + f * S::template pitch_for<PM>());
             });
             ex.barrier();
         }
-        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, P + 1>(ex, lds_raw, tw, src, dst);
+        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, P + 1>(ex, lds_raw, tw, src, dst);
     }
 }
 
@@ -235,13 +264,13 @@ template <class L> MI_HD ElemSrc<L> elem_src(L l) { return ElemSrc<L>{l}; }
 // register array length an executor must provide per thread
 template <class S, bool SPLIT> constexpr int regs_needed() { return S::emax(); }
 // LDS bytes one workgroup needs
-template <class T, class S, int F, bool SPLIT> constexpr size_t lds_bytes() {
-    return (S::NP > 1) ? (size_t)F * S::pitch() * (SPLIT ? sizeof(T) : sizeof(cx<T>)) : 0;
+template <class T, class S, int F, bool SPLIT, int PM = 1> constexpr size_t lds_bytes() {
+    return (S::NP > 1) ? (size_t)F * S::template pitch_for<PM>() * (SPLIT ? sizeof(T) : sizeof(cx<T>)) : 0;
 }
 
 // SRC_IN_LDS: `src` reads the same LDS buffer the exchanges use (Rader/Bluestein second transform), so a
 // barrier separates the loads from the first scatter.
-template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, bool SRC_IN_LDS = false, class X, class SRC, class DST>
+template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, bool SRC_IN_LDS = false, int PM = 1, class X, class SRC, class DST>
 MI_HD void wg_fft(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC src, DST dst) {
     static_assert(S::valid(), "radices must multiply to N");
     constexpr int R0 = S::R[0], NB0 = S::nb(0), BPT0 = S::bpt(0);
@@ -259,7 +288,7 @@ MI_HD void wg_fft(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC src, DS
         });
     });
     if constexpr (SRC_IN_LDS) ex.barrier();
-    wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, 0>(ex, lds_raw, tw, src, dst);
+    wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, 0>(ex, lds_raw, tw, src, dst);
 }
 
 }  // namespace mi355

@@ -45,6 +45,10 @@ MI_HD void k1_body(X& ex, const K1Params<T>& p, long long block, void* lds) {
     wg_fft<T, S, F, MAP_EF, MAP_EF, SPLIT>(ex, lds, p.tw, elem_src(src), dst);
 }
 
+// LDS pitch residue for a tile of F columns: lanes walk across the columns first, so the (32 / F) row slots of one
+// 32-lane group must fall on the banks the columns leave free
+constexpr int k2_pitch_mod(int f) { return f < 32 ? 32 / f : 1; }
+
 // Source of a large-N pass: F-element row segments, times the inter-pass twiddle w_Q^{c j} (Q = S R,
 // c = B mod S, j = row).  A thread's butterfly needs rows j = b + k nb, k = 0..R-1, so
 //     w^{c j} = w^{c b} * (w^{c nb})^k :
@@ -129,7 +133,7 @@ MI_HD void k2_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     };
     // first pass: lanes walk across the tile's columns on the way in and along each sequence on the way
     // out (the F*R output block is contiguous); later passes: across columns both ways
-    wg_fft<T, S, F, MAP_FF, FIRST ? MAP_EF : MAP_FF, SPLIT>(ex, lds, p.tw, src, dst);
+    wg_fft<T, S, F, MAP_FF, FIRST ? MAP_EF : MAP_FF, SPLIT, false, k2_pitch_mod(F)>(ex, lds, p.tw, src, dst);
 }
 
 // ---- Bluestein: any length n <= (M + 1) / 2 through two length-M workgroup transforms ---------------------

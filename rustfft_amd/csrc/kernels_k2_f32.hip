@@ -11,7 +11,8 @@ void register_k2_f32(std::vector<KernelEntry>& reg) {
     // one after the other so two workgroups fit a CU's LDS; the twiddled sub-passes are radix 8 (fewer live twiddles)
     MI_K2(float, 32, 16, true, 1024, 32, 8, 8, 16);
     MI_K2V(1, float, 32, 8, false, 1024, 64, 16, 16, 4);   // tuning: 64-byte row segments paired per XCD, full-complex exchange
-    MI_K2V(2, float, 32, 16, true, 1024, 32, 16, 8, 8);    // tuning: radix-16 first sub-pass
-    MI_K2V(3, float, 32, 16, false, 1024, 64, 16, 16, 4);  // tuning: 1024 threads, one workgroup per CU
+    MI_K2V(2, float, 32, 16, true, 1024, 32, 32, 32);      // tuning: two radix-32 sub-passes, a single exchange
+    MI_K2V(3, float, 32, 8, true, 1024, 32, 8, 8, 16);     // tuning: 8-column tiles (paired per XCD), 256 threads, four workgroups per CU
+    MI_K2V(4, float, 32, 8, true, 1024, 32, 32, 32);
 }
 }  // namespace mi355

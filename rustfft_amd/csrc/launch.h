@@ -62,17 +62,17 @@ template <class T, class S, int F, bool FIRST, bool SPLIT> KernelEntry make_k2(i
     e.f = F;
     fill_sched<S>(e);
     e.threads = F * S::TPF;
-    e.lds_bytes = lds_bytes<T, S, F, SPLIT>();
+    e.lds_bytes = lds_bytes<T, S, F, SPLIT, k2_pitch_mod(F)>();
     e.split = SPLIT;
     e.name = name;
     e.launch = [](const void* params, long long grid, void* stream) {
         void* args[] = {const_cast<void*>(params)};
         (void)hipLaunchKernel((const void*)k2_kernel<T, S, F, FIRST, SPLIT>, dim3((unsigned)grid), dim3(F * S::TPF), args,
-                              lds_bytes<T, S, F, SPLIT>(), (hipStream_t)stream);
+                              lds_bytes<T, S, F, SPLIT, k2_pitch_mod(F)>(), (hipStream_t)stream);
     };
     e.prepare = []() -> int {
         return (int)hipFuncSetAttribute((const void*)k2_kernel<T, S, F, FIRST, SPLIT>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<T, S, F, SPLIT>());
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<T, S, F, SPLIT, k2_pitch_mod(F)>());
     };
     return e;
 }
@@ -192,11 +192,11 @@ template <class T, class S, int F, bool FIRST, bool SPLIT> KernelEntry make_k2(i
     e.f = F;
     fill_sched<S>(e);
     e.threads = F * S::TPF;
-    e.lds_bytes = lds_bytes<T, S, F, SPLIT>();
+    e.lds_bytes = lds_bytes<T, S, F, SPLIT, k2_pitch_mod(F)>();
     e.split = SPLIT;
     e.name = name;
     e.launch = [](const void* params, long long grid, void*) {
-        std::vector<char> lds(lds_bytes<T, S, F, SPLIT>() + 64, (char)0x5a);
+        std::vector<char> lds(lds_bytes<T, S, F, SPLIT, k2_pitch_mod(F)>() + 64, (char)0x5a);
         for (long long b = 0; b < grid; ++b) {
             HostExec<T, regs_needed<S, SPLIT>()> ex(F * S::TPF);
             k2_body<T, S, F, FIRST, SPLIT>(ex, *(const K2Params<T>*)params, b, lds.data());

@@ -32,6 +32,29 @@ template <class V, int F, int R, int NT> __global__ __launch_bounds__(NT) void t
         for (int k = 0; k < E; ++k) dstc[threadIdx.x + k * NT] = v[k];
     }
 }
+// same as tilecopy, but carrying `LDSB` bytes of dynamic LDS per workgroup to impose the occupancy the FFT tiles have
+template <class V, int F, int R, int NT> __global__ __launch_bounds__(NT) void tilecopy_lds(const V* __restrict__ in, V* __restrict__ out, size_t M, int strided_out) {
+    extern __shared__ char smem[];
+    constexpr int E = F * R / NT;
+    const size_t tiles = M / F;
+    const size_t g = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const V* src = in + g * M * R + tile * F;
+    V* dsto = out + g * M * R + tile * F;
+    V* dstc = out + ((size_t)blockIdx.x) * (F * R);
+    const int f = threadIdx.x % F, u = threadIdx.x / F;
+    V v[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) v[k] = src[f + (size_t)(u + k * (NT / F)) * M];
+    if (threadIdx.x == 0 && M == 1) smem[0] = 1;  // keep the allocation alive
+    __syncthreads();
+    if (strided_out) {
+#pragma unroll
+        for (int k = 0; k < E; ++k) dsto[f + (size_t)(u + k * (NT / F)) * M] = v[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < E; ++k) dstc[threadIdx.x + k * NT] = v[k];
+    }
+}
 template <class K> float time_it(K&& launch, int reps = 5) {
     hipEvent_t a, b;
     hipEventCreate(&a);
@@ -70,6 +93,17 @@ int main() {
     report("tile 512x16 float2 rd-strided wr-strided (M=2048)", time_it([&] { tilecopy<float2, 16, 512, 512><<<batch * (2048 / 16), 512>>>((float2*)a, (float2*)b, 2048, 1); }));
     report("tile 256x32 float2 rd-strided wr-strided (M=4096)", time_it([&] { tilecopy<float2, 32, 256, 512><<<batch * (4096 / 32), 512>>>((float2*)a, (float2*)b, 4096, 1); }));
     report("tile 1024x8 float4 rd-strided wr-strided", time_it([&] { tilecopy<float4, 8, 1024, 512><<<(bytes / 16 / n) * (1024 / 8), 512>>>((float4*)a, (float4*)b, 1024, 1); }));
+    for (int lds : {0, 70000, 140000}) {
+        char nm[128];
+        hipFuncSetAttribute((const void*)tilecopy_lds<float2, 16, 1024, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150000);
+        snprintf(nm, sizeof nm, "tile 1024x16 512thr x32, LDS %d, wr-contig", lds);
+        report(nm, time_it([&] { tilecopy_lds<float2, 16, 1024, 512><<<batch * 64, 512, lds>>>((float2*)a, (float2*)b, 1024, 0); }));
+        snprintf(nm, sizeof nm, "tile 1024x16 512thr x32, LDS %d, wr-strided", lds);
+        report(nm, time_it([&] { tilecopy_lds<float2, 16, 1024, 512><<<batch * 64, 512, lds>>>((float2*)a, (float2*)b, 1024, 1); }));
+        hipFuncSetAttribute((const void*)tilecopy_lds<float2, 32, 256, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 150000);
+        snprintf(nm, sizeof nm, "tile 256x32 512thr x16, LDS %d, wr-strided (M=4096)", lds);
+        report(nm, time_it([&] { tilecopy_lds<float2, 32, 256, 512><<<batch * 128, 512, lds>>>((float2*)a, (float2*)b, 4096, 1); }));
+    }
     hipMemcpy(b, a, bytes, hipMemcpyDeviceToDevice);
     report("hipMemcpy D2D", time_it([&] { hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0); }));
     return 0;

@@ -50,7 +50,7 @@ def main():
         alg = batch * 2 * n * esz
         print(json.dumps({"n": n, "log2n": round(p, 3), "batch": batch, "ms": round(ms, 4), "gflops": round(batch * 5.0 * n * p / ms / 1e6, 1),
                           "alg_GBps": round(alg / ms / 1e6, 1), "kernel_ms": [round(k, 4) for k in kms],
-                          "kernel_GBps": [round(alg / k / 1e6, 1) for k in kms], "plan": fft.describe()}), flush=True)
+                          "kernel_GBps": [round(alg / k / 1e6, 1) if k > 0 else None for k in kms], "plan": fft.describe()}), flush=True)
         del x
 
 
