@@ -174,6 +174,87 @@ MI_HD void bluestein_body(X& ex, const BluesteinParams<T>& p, long long block, v
     (void)M;
 }
 
+// ---- run-time scheduled batched transform (13-smooth lengths) ------------------------------------------------
+template <class T, int EMAX, bool LIGHT, class X>
+MI_HD void dyn_k1_body(X& ex, const DynK1Params<T>& p, long long block, void* lds) {
+    const DynSched& s = p.s;
+    const long long fft0 = block * s.f;
+    const int n = s.n;
+    const cx<T>* MI_RESTRICT in = p.in + fft0 * n;
+    cx<T>* MI_RESTRICT out = p.out + fft0 * n;
+    const int rows = (int)((p.batch - fft0) < s.f ? (p.batch - fft0) : s.f);
+    const T sgn = p.sgn;
+    auto src = [=](int f, int i) -> cx<T> {
+        if (f < rows) {
+            cx<T> x = in[(unsigned)(f * n + i)];
+            x.im *= sgn;
+            return x;
+        }
+        return cx<T>{0, 0};
+    };
+    auto dst = [=](int f, int i, cx<T> x) {
+        if (f < rows) {
+            x.im *= sgn;
+            out[(unsigned)(f * n + i)] = x;
+        }
+    };
+    wg_fft_dyn<T, EMAX, LIGHT>(ex, s, lds, p.tw, src, dst);
+}
+
+// ---- run-time scheduled Rader (any prime p with 13-smooth p - 1); same steps as rader_body ---------------------
+template <class T, int EMAX, bool LIGHT, class X>
+MI_HD void dyn_rader_body(X& ex, const DynRaderParams<T>& p, long long block, void* lds) {
+    const DynSched& s = p.s;
+    const int M = s.n, P = s.n + 1, PITCH = s.pitch, F = s.f, NT = s.f * s.tpf;
+    const long long fft0 = block * F;
+    const cx<T>* MI_RESTRICT in = p.in;
+    cx<T>* MI_RESTRICT out = p.out;
+    const cx<T>* MI_RESTRICT dtab = p.d;
+    const int* MI_RESTRICT perm_in = p.perm_in;
+    const int* MI_RESTRICT perm_out = p.perm_out;
+    const T sgn = p.sgn;
+    cx<T>* work = (cx<T>*)lds;
+    cx<T>* rows = work + F * PITCH;
+    const long long rows_here = (p.batch - fft0) < F ? (p.batch - fft0) : F;
+    const int valid = (int)(rows_here * P);
+    ex.for_threads([&](int tid, cx<T>*) {
+        for (int t = tid; t < F * P; t += NT) {
+            cx<T> x = cx<T>{0, 0};
+            if (t < valid) {
+                x = in[fft0 * P + t];
+                x.im *= sgn;
+            }
+            rows[t] = x;
+        }
+    });
+    ex.barrier();
+    auto src1 = [=](int f, int j) -> cx<T> { return rows[f * P + perm_in[j]]; };
+    auto dst1 = [=](int f, int j, cx<T> v) {
+        cx<T> t = cconj(v * dtab[j]);
+        if (j == 0) {
+            // rows[f*P] (= x[0]) is read by nobody else: the g^k gather never touches index 0
+            const cx<T> x0 = rows[f * P];
+            t = t + cconj(x0);
+            rows[f * P] = x0 + v;  // X[0]
+        }
+        work[f * PITCH + j] = t;
+    };
+    wg_fft_dyn<T, EMAX, LIGHT>(ex, s, lds, p.tw, src1, dst1);
+    ex.barrier();
+    auto src2 = [=](int f, int i) -> cx<T> { return work[f * PITCH + i]; };
+    auto dst2 = [=](int f, int j, cx<T> v) { rows[f * P + perm_out[j]] = cconj(v); };
+    wg_fft_dyn<T, EMAX, LIGHT, true>(ex, s, lds, p.tw, src2, dst2);
+    ex.barrier();
+    ex.for_threads([&](int tid, cx<T>*) {
+        for (int t = tid; t < valid; t += NT) {
+            cx<T> y = rows[t];
+            y.im *= sgn;
+            out[fft0 * P + t] = y;
+        }
+    });
+    (void)M;
+}
+
 // ---- element-wise stages of the multi-kernel Bluestein (one thread per output element, grid-stride) ---------
 template <class T> MI_HD void pointwise_elem(const PointwiseParams<T>& p, long long idx) {
     if (p.stage == 0) {

@@ -8,5 +8,7 @@ void register_np2_f32(std::vector<KernelEntry>& reg) {
     MI_RADER(float, 32, 2, 1008, 144, 16, 9, 7);
     MI_BS_LIST(float, 32);
     reg.push_back(make_pointwise<float>(32));
+    reg.push_back(make_dyn_k1<float>(32));
+    reg.push_back(make_dyn_rader<float>(32));
 }
 }  // namespace mi355

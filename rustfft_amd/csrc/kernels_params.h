@@ -1,6 +1,7 @@
 // Launch-parameter blocks of the kernels (plain data; shared by the kernels and the host planner).
 #pragma once
 #include "cx.h"
+#include "dyn_engine.h"
 
 namespace mi355 {
 
@@ -57,6 +58,28 @@ template <class T> struct RaderParams {
     long long batch;
     int p;
     T sgn;
+};
+
+// Run-time scheduled variants (dyn_engine.h): any 13-smooth length that fits one workgroup, and Rader for any
+// prime p whose p - 1 is 13-smooth.
+template <class T> struct DynK1Params {
+    const cx<T>* in;
+    cx<T>* out;
+    const cx<T>* tw;
+    long long batch;
+    T sgn;
+    DynSched s;
+};
+template <class T> struct DynRaderParams {
+    const cx<T>* in;
+    cx<T>* out;
+    const cx<T>* tw;
+    const cx<T>* d;
+    const int* perm_in;
+    const int* perm_out;
+    long long batch;
+    T sgn;
+    DynSched s;  // schedule of the inner length p - 1
 };
 
 // Element-wise stages of the multi-kernel Bluestein used for lengths that do not fit one workgroup

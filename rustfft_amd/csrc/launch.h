@@ -152,6 +152,56 @@ template <class T, class S, int F> KernelEntry make_rader(int prec, const char* 
     };
     return e;
 }
+constexpr int kDynEmax = 16, kDynEmaxLight = 12;
+template <class T, bool LIGHT> __global__ __launch_bounds__(512) void dyn_k1_kernel(DynK1Params<T> p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevExec<T, LIGHT ? kDynEmaxLight : kDynEmax> ex;
+    dyn_k1_body<T, LIGHT ? kDynEmaxLight : kDynEmax, LIGHT>(ex, p, (long long)blockIdx.x, smem);
+}
+template <class T, bool LIGHT> __global__ __launch_bounds__(512) void dyn_rader_kernel(DynRaderParams<T> p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevExec<T, LIGHT ? kDynEmaxLight : kDynEmax> ex;
+    dyn_rader_body<T, LIGHT ? kDynEmaxLight : kDynEmax, LIGHT>(ex, p, (long long)blockIdx.x, smem);
+}
+// the run-time scheduled kernels take their block size and LDS bytes from the schedule in the parameter block
+template <class T> KernelEntry make_dyn_k1(int prec) {
+    KernelEntry e{};
+    e.kind = KIND_DYN_K1;
+    e.prec = prec;
+    e.name = "dyn_k1";
+    e.launch = [](const void* params, long long grid, void* stream) {
+        const DynK1Params<T>* p = (const DynK1Params<T>*)params;
+        void* args[] = {const_cast<void*>(params)};
+        (void)hipLaunchKernel(p->s.light ? (const void*)dyn_k1_kernel<T, true> : (const void*)dyn_k1_kernel<T, false>,
+                              dim3((unsigned)grid), dim3(p->s.f * p->s.tpf), args, (size_t)p->s.f * p->s.pitch * sizeof(cx<T>),
+                              (hipStream_t)stream);
+    };
+    e.prepare = []() -> int {
+        int a = (int)hipFuncSetAttribute((const void*)dyn_k1_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        int b = (int)hipFuncSetAttribute((const void*)dyn_k1_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return a ? a : b;
+    };
+    return e;
+}
+template <class T> KernelEntry make_dyn_rader(int prec) {
+    KernelEntry e{};
+    e.kind = KIND_DYN_RADER;
+    e.prec = prec;
+    e.name = "dyn_rader";
+    e.launch = [](const void* params, long long grid, void* stream) {
+        const DynRaderParams<T>* p = (const DynRaderParams<T>*)params;
+        void* args[] = {const_cast<void*>(params)};
+        (void)hipLaunchKernel(p->s.light ? (const void*)dyn_rader_kernel<T, true> : (const void*)dyn_rader_kernel<T, false>,
+                              dim3((unsigned)grid), dim3(p->s.f * p->s.tpf), args,
+                              (size_t)p->s.f * (p->s.pitch + p->s.n + 1) * sizeof(cx<T>), (hipStream_t)stream);
+    };
+    e.prepare = []() -> int {
+        int a = (int)hipFuncSetAttribute((const void*)dyn_rader_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        int b = (int)hipFuncSetAttribute((const void*)dyn_rader_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return a ? a : b;
+    };
+    return e;
+}
 #else
 // -------------------------------------------------------------------------------- host emulator
 template <class T, int NREG> struct HostExec {
@@ -255,6 +305,45 @@ template <class T, class S, int F> KernelEntry make_rader(int prec, const char* 
         for (long long b = 0; b < grid; ++b) {
             HostExec<T, regs_needed<S, false>()> ex(F * S::TPF);
             rader_body<T, S, F>(ex, *(const RaderParams<T>*)params, b, lds.data());
+        }
+    };
+    e.prepare = []() -> int { return 0; };
+    return e;
+}
+constexpr int kDynEmax = 16, kDynEmaxLight = 12;
+template <class T> KernelEntry make_dyn_k1(int prec) {
+    KernelEntry e{};
+    e.kind = KIND_DYN_K1;
+    e.prec = prec;
+    e.name = "dyn_k1";
+    e.launch = [](const void* params, long long grid, void*) {
+        const DynK1Params<T>* p = (const DynK1Params<T>*)params;
+        std::vector<char> lds((size_t)p->s.f * p->s.pitch * sizeof(cx<T>) + 64, (char)0x5a);
+        for (long long b = 0; b < grid; ++b) {
+            HostExec<T, kDynEmax> ex(p->s.f * p->s.tpf);
+            if (p->s.light)
+                dyn_k1_body<T, kDynEmaxLight, true>(ex, *p, b, lds.data());
+            else
+                dyn_k1_body<T, kDynEmax, false>(ex, *p, b, lds.data());
+        }
+    };
+    e.prepare = []() -> int { return 0; };
+    return e;
+}
+template <class T> KernelEntry make_dyn_rader(int prec) {
+    KernelEntry e{};
+    e.kind = KIND_DYN_RADER;
+    e.prec = prec;
+    e.name = "dyn_rader";
+    e.launch = [](const void* params, long long grid, void*) {
+        const DynRaderParams<T>* p = (const DynRaderParams<T>*)params;
+        std::vector<char> lds((size_t)p->s.f * (p->s.pitch + p->s.n + 1) * sizeof(cx<T>) + 64, (char)0x5a);
+        for (long long b = 0; b < grid; ++b) {
+            HostExec<T, kDynEmax> ex(p->s.f * p->s.tpf);
+            if (p->s.light)
+                dyn_rader_body<T, kDynEmaxLight, true>(ex, *p, b, lds.data());
+            else
+                dyn_rader_body<T, kDynEmax, false>(ex, *p, b, lds.data());
         }
     };
     e.prepare = []() -> int { return 0; };

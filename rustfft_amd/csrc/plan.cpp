@@ -195,6 +195,85 @@ static uint64_t primitive_root(uint64_t p) {
     return 0;
 }
 
+// Run-time schedule for a 13-smooth length (dyn_engine.h): greedy largest-radix factorisation over the compiled
+// butterfly set, threads per sequence from the 16-value register budget, sequences per workgroup from LDS.
+static bool build_dyn_sched(size_t n, size_t esz, size_t extra_lds_elems_per_seq, DynSched& s) {
+    static const int allowed_full[] = {16, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
+    static const int allowed_light[] = {12, 10, 9, 8, 6, 5, 4, 3, 2};  // dyn_engine.h LIGHT set (lengths 2^a 3^b 5^c)
+    if (n < 2 || n > 16384) return false;
+    std::vector<int> radices;
+    bool light = true;
+    {
+        size_t t = n;
+        for (int q : {2, 3, 5})
+            while (t % q == 0) t /= q;
+        light = (t == 1);
+    }
+    const int* allowed = light ? allowed_light : allowed_full;
+    const int n_allowed = light ? 9 : 13;
+    const int emax = light ? 12 : 16;
+    size_t rem = n;
+    while (rem > 1) {
+        int pick = 0;
+        for (int i = 0; i < n_allowed; ++i)
+            if (rem % allowed[i] == 0) {
+                pick = allowed[i];
+                break;
+            }
+        if (!pick) return false;  // a prime factor above 13
+        radices.push_back(pick);
+        rem /= pick;
+    }
+    if ((int)radices.size() > kDynMaxPass) return false;
+    std::sort(radices.begin(), radices.end(), std::greater<int>());
+    s = DynSched{};
+    s.n = (int)n;
+    s.light = light ? 1 : 0;
+    s.np = (int)radices.size();
+    int tpf = 1, stride = 1, off = 0;
+    for (int p = 0; p < s.np; ++p) {
+        const int R = radices[p], nb = (int)n / R, per_thread = emax / R;
+        tpf = std::max(tpf, (nb + per_thread - 1) / per_thread);
+        s.radix[p] = R;
+        s.nb[p] = nb;
+        s.stride[p] = stride;
+        s.rcp_stride[p] = stride > 1 ? (unsigned)((((unsigned long long)1 << 32) + stride - 1) / stride) : 0;
+        s.tw_off[p] = off;
+        if (p >= 1) off += (R - 1) * stride;
+        stride *= R;
+    }
+    if (tpf > 512) return false;  // the kernels are compiled for at most 512 threads per workgroup
+    s.tpf = tpf;
+    s.rcp_tpf = tpf > 1 ? (unsigned)((((unsigned long long)1 << 32) + tpf - 1) / tpf) : 0;
+    for (int p = 0; p < s.np; ++p) s.bpt[p] = (s.nb[p] + tpf - 1) / tpf;
+    s.pitch = (dyn_phys((int)n - 1) + 1) | 1;
+    const size_t per_seq = ((size_t)s.pitch + extra_lds_elems_per_seq) * esz;
+    int f = std::max(1, 256 / tpf);
+    while (f > 1 && (size_t)f * per_seq > 64 * 1024) --f;
+    while (f > 1 && f * tpf > 512) --f;
+    if ((size_t)f * per_seq > 150 * 1024 || f * tpf > 512) return false;
+    s.f = f;
+    return true;
+}
+template <class T> static std::vector<T> build_dyn_twiddles(const DynSched& s) {
+    std::vector<T> t;
+    for (int p = 1; p < s.np; ++p)
+        for (int kk = 1; kk < s.radix[p]; ++kk)
+            for (int r = 0; r < s.stride[p]; ++r) push_tw<T>(t, (size_t)r * kk, (size_t)s.stride[p] * s.radix[p]);
+    return t;
+}
+static const KernelEntry* find_kind(int kind, int prec) {
+    for (auto& e : registry())
+        if (e.kind == kind && e.prec == prec) return &e;
+    return nullptr;
+}
+static bool is_prime_sz(size_t n) {
+    if (n < 2) return false;
+    for (size_t d = 2; d * d <= n; ++d)
+        if (n % d == 0) return false;
+    return true;
+}
+
 // choose macro radices r_1..r_P (each with a FIRST and a LATER kernel) whose product is n:
 // fewest passes, then the most balanced split, larger radices first.
 static bool choose_macro_radices(int prec, size_t n, std::vector<size_t>& out) {
@@ -322,6 +401,57 @@ template <class T> static int build_plan_t(Plan& plan) {
         plan.passes.push_back(pd);
         return MI355FFT_OK;
     }
+    // 13-smooth lengths that fit one workgroup: the run-time scheduled mixed-radix kernel (the RadixN analogue)
+    if (env_int("MI355FFT_NO_DYN") == 0) {
+        DynSched ds;
+        const KernelEntry* dk = find_kind(KIND_DYN_K1, plan.prec);
+        if (dk && build_dyn_sched(n, 2 * sizeof(T), 0, ds)) {
+            if (dk->prepare()) return MI355FFT_ERR_HIP;
+            plan.kind = PLAN_SINGLE;
+            PassDesc pd{};
+            pd.k = dk;
+            pd.dyn = ds;
+            pd.d_tw = upload<T>(plan, build_dyn_twiddles<T>(ds), &rc);
+            if (rc) return rc;
+            plan.passes.push_back(pd);
+            return MI355FFT_OK;
+        }
+        // primes whose p - 1 is 13-smooth: run-time scheduled Rader (raders_algorithm.rs:65-124 tables in f64)
+        const KernelEntry* rk = find_kind(KIND_DYN_RADER, plan.prec);
+        // (measured slower than the one-workgroup Bluestein on MI355X, so it is opt-in: MI355FFT_DYN_RADER=1)
+        if (rk && env_int("MI355FFT_DYN_RADER") && is_prime_sz(n) && n > 3 && build_dyn_sched(n - 1, 2 * sizeof(T), n, ds)) {
+            if (rk->prepare()) return MI355FFT_ERR_HIP;
+            const uint64_t pp = n, g = primitive_root(pp), ginv = modpow(g, pp - 2, pp);
+            std::vector<cd> d(pp - 1);
+            std::vector<int> pin(pp - 1), pout(pp - 1);
+            uint64_t ti = 1, a = 1, b = 1;
+            for (size_t j = 0; j + 1 < pp; ++j) {
+                double re, im;
+                twiddle_f64(ti, pp, &re, &im);
+                d[j] = cd(re, im) / (double)(pp - 1);
+                ti = ti * ginv % pp;
+                a = a * g % pp;
+                b = b * ginv % pp;
+                pin[j] = (int)a;
+                pout[j] = (int)b;
+            }
+            host_dft(d);
+            plan.kind = PLAN_RADER;
+            PassDesc pd{};
+            pd.k = rk;
+            pd.dyn = ds;
+            pd.d_tw = upload<T>(plan, build_dyn_twiddles<T>(ds), &rc);
+            if (rc) return rc;
+            pd.d_aux1 = upload<T>(plan, to_interleaved<T>(d), &rc);
+            if (rc) return rc;
+            pd.d_perm_in = upload<int>(plan, pin, &rc);
+            if (rc) return rc;
+            pd.d_perm_out = upload<int>(plan, pout, &rc);
+            if (rc) return rc;
+            plan.passes.push_back(pd);
+            return MI355FFT_OK;
+        }
+    }
     // any other length that fits one workgroup: Bluestein over the smallest compiled M >= 2n - 1
     {
         const KernelEntry* best = nullptr;
@@ -399,7 +529,15 @@ std::string Plan::describe() const {
         s << "bluestein_large(M=" << inner->len << ": " << inner->describe() << ")";
         return s.str();
     }
-    for (size_t i = 0; i < passes.size(); ++i) s << (i ? " -> " : "") << passes[i].k->name;
+    for (size_t i = 0; i < passes.size(); ++i) {
+        s << (i ? " -> " : "") << passes[i].k->name;
+        if (passes[i].k->kind == KIND_DYN_K1 || passes[i].k->kind == KIND_DYN_RADER) {
+            const DynSched& d = passes[i].dyn;
+            s << "<" << d.n << ", " << d.tpf;
+            for (int q = 0; q < d.np; ++q) s << ", " << d.radix[q];
+            s << ">xF" << d.f;
+        }
+    }
     return s.str();
 }
 
@@ -434,6 +572,29 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         p.batch = (long long)batch;
         p.sgn = inverse ? (T)-1 : (T)1;
         grid = (long long)((batch + k.f - 1) / k.f);
+        k.launch(&p, grid, stream);
+    } else if (k.kind == KIND_DYN_K1) {
+        DynK1Params<T> p{};
+        p.in = (const cx<T>*)in;
+        p.out = (cx<T>*)out;
+        p.tw = (const cx<T>*)pd.d_tw;
+        p.batch = (long long)batch;
+        p.sgn = inverse ? (T)-1 : (T)1;
+        p.s = pd.dyn;
+        grid = (long long)((batch + pd.dyn.f - 1) / pd.dyn.f);
+        k.launch(&p, grid, stream);
+    } else if (k.kind == KIND_DYN_RADER) {
+        DynRaderParams<T> p{};
+        p.in = (const cx<T>*)in;
+        p.out = (cx<T>*)out;
+        p.tw = (const cx<T>*)pd.d_tw;
+        p.d = (const cx<T>*)pd.d_aux1;
+        p.perm_in = (const int*)pd.d_perm_in;
+        p.perm_out = (const int*)pd.d_perm_out;
+        p.batch = (long long)batch;
+        p.sgn = inverse ? (T)-1 : (T)1;
+        p.s = pd.dyn;
+        grid = (long long)((batch + pd.dyn.f - 1) / pd.dyn.f);
         k.launch(&p, grid, stream);
     } else if (k.kind == KIND_BLUESTEIN) {
         BluesteinParams<T> p{};

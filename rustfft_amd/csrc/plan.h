@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/mi355fft.h"
+#include "dyn_engine.h"
 #include "registry.h"
 
 namespace mi355 {
@@ -24,6 +25,7 @@ struct PassDesc {
     void* d_aux2;  // Bluestein: bf[M]
     void* d_perm_in;   // Rader: g^(j+1) mod p
     void* d_perm_out;  // Rader: g^-(j+1) mod p
+    DynSched dyn;      // run-time schedule (KIND_DYN_K1 / KIND_DYN_RADER)
 };
 
 struct Workspace {

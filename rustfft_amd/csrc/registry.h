@@ -7,7 +7,7 @@
 
 namespace mi355 {
 
-enum KernelKind { KIND_K1 = 1, KIND_K2_FIRST = 2, KIND_K2_LATER = 3, KIND_RADER = 4, KIND_BLUESTEIN = 5, KIND_POINTWISE = 6 };
+enum KernelKind { KIND_K1 = 1, KIND_K2_FIRST = 2, KIND_K2_LATER = 3, KIND_RADER = 4, KIND_BLUESTEIN = 5, KIND_POINTWISE = 6, KIND_DYN_K1 = 7, KIND_DYN_RADER = 8 };
 
 struct KernelEntry {
     int kind;

@@ -296,3 +296,28 @@ def test_lengths_beyond_one_workgroup(planners, oracle, dtype):
             y = x.copy()
             fft.process(y)
             assert rel_l2(y, numpy_fft(x, n, d == 1)) < REL[np.dtype(dtype)], (n, d)
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_runtime_scheduled_kernels(planners, oracle, dtype):
+    """13-smooth lengths (run-time scheduled mixed radix, the RadixN analogue) and primes with 13-smooth p - 1
+    (run-time scheduled Rader) vs the oracle's planner choice, all four API modes."""
+    planner = planners[np.dtype(dtype)]
+    for n in [3, 5, 6, 7, 9, 10, 11, 12, 13, 15, 18, 21, 22, 26, 35, 45, 49, 60, 77, 91, 100, 121, 143, 169, 243, 360, 625, 720, 1000,
+              1001, 1331, 2187, 2310, 3000, 4095]:
+        for d in (0, 1):
+            fft = planner.plan_fft(n, d)
+            assert "dyn_k1" in fft.describe(), (n, fft.describe())
+            check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=5 if n < 512 else 3)
+    import os
+
+    import rustfft_amd
+
+    os.environ["MI355FFT_DYN_RADER"] = "1"  # opt-in path (read at plan creation); the default for these primes is Bluestein
+    fresh = rustfft_amd.FftPlanner(dtype)
+    for p in [5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 53, 61, 67, 71, 73, 79, 89, 97, 127, 211, 257, 331, 1201, 2311, 3001]:
+        for d in (0, 1):
+            fft = fresh.plan_fft(p, d)
+            assert "dyn_rader" in fft.describe()
+            check_fft_algorithm(fft, p, d, reference=oracle.plan(dtype, p, d), n=3)
+    del os.environ["MI355FFT_DYN_RADER"]

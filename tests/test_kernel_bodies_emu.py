@@ -180,5 +180,31 @@ def test_lengths_beyond_one_workgroup(emu_planner, oracle, dtype):
     for n in (4097, 5000, 5759, 10007, 101 * 103):
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
-            assert "bluestein_large" in fft.describe()
+            assert ("dyn_k1" if n == 5000 else "bluestein_large") in fft.describe()
             check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=2)
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_runtime_scheduled_kernels(emu_planner, oracle, dtype):
+    """dyn_engine.h: 13-smooth lengths through the run-time scheduled mixed-radix kernel (the RadixN analogue,
+    src/algorithm/radixn.rs:497-541 covers factors 2..7 over small bases; here every compiled radix appears) and
+    primes with 13-smooth p - 1 through the run-time scheduled Rader (raders_algorithm.rs:302-309: primes < 100)."""
+    planner = emu_planner(dtype)
+    smooth = [3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 18, 20, 21, 22, 24, 26, 27, 33, 35, 39, 45, 48, 49, 55, 60, 63, 65, 77, 80,
+              81, 91, 96, 100, 120, 121, 125, 143, 144, 169, 210, 243, 343, 360, 625, 720, 1000, 1001, 1331, 2187, 2310, 3000, 4095]
+    for n in smooth:
+        for d in (0, 1):
+            fft = planner.plan_fft(n, d)
+            assert "dyn_k1" in fft.describe(), (n, fft.describe())
+            check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=5 if n < 512 else 3)
+    primes = [p for p in range(5, 100) if all(p % q for q in range(2, int(p**0.5) + 1))] + [127, 211, 257, 331, 1201, 2311, 3001]
+    import os
+
+    os.environ["MI355FFT_DYN_RADER"] = "1"  # opt-in path (read at plan creation); the default for these primes is Bluestein
+    planner = emu_planner(dtype)  # fresh planner: no cached Bluestein plans for these lengths
+    for p in primes:
+        for d in (0, 1):
+            fft = planner.plan_fft(p, d)
+            check_fft_algorithm(fft, p, d, reference=oracle.plan(dtype, p, d), n=3)
+    assert "dyn_rader" in planner.plan_fft(1201, 0).describe() and "dyn_rader" in planner.plan_fft(97, 0).describe()
+    del os.environ["MI355FFT_DYN_RADER"]
