@@ -519,6 +519,7 @@ template <class T> static int build_plan_t(Plan& plan) {
 
 int build_plan(Plan& plan) {
     ensure_registry();
+    plan.dbg = env_int("MI355FFT_DBG");  // measurement knobs, read once per plan (0 in production)
     return plan.prec == 32 ? build_plan_t<float>(plan) : build_plan_t<double>(plan);
 }
 
@@ -637,11 +638,11 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         p.tiles_per_fft = pd.m / k.f;
         p.sgn_in = (inverse && pi == 0) ? (T)-1 : (T)1;
         p.sgn_out = (inverse && pi + 1 == plan.passes.size()) ? (T)-1 : (T)1;
-        p.dbg = env_int("MI355FFT_DBG");
+        p.dbg = plan.dbg;
         {
             const long long seg = (long long)k.f * (long long)(2 * sizeof(T));
             long long pair = seg < 128 ? 128 / seg : 1;
-            if ((p.tiles_per_fft * (long long)batch) % (8 * pair) != 0 || (env_int("MI355FFT_DBG") & 2)) pair = 1;
+            if ((p.tiles_per_fft * (long long)batch) % (8 * pair) != 0 || (plan.dbg & 2)) pair = 1;
             p.pair = (int)pair;
         }
         grid = (long long)batch * p.tiles_per_fft;

@@ -47,6 +47,7 @@ struct Plan {
     std::vector<PassDesc> passes;
     std::vector<void*> device_allocs;
     size_t chunk_batch = 0;
+    int dbg = 0;
     std::mutex ws_mutex;
     std::map<void*, Workspace> workspaces;  // one HBM workspace per stream
     std::mutex host_mutex;                  // serialises the host-slice staging path
