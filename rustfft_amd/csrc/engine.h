@@ -68,7 +68,9 @@ template <int N_, int TPF_, int... Rs> struct Sched {
     static constexpr int paddiv() { return (!all_pow2() && NP > 1 && R[0] % 2 == 0) ? R[0] : 0; }
     static constexpr int phys(int i) {
         constexpr int d = paddiv();
-        if constexpr (d != 0)
+        if constexpr (all_pow2() && emax() > 16)
+            return i + i / 32;
+        else if constexpr (d != 0)
             return i + i / d;
         else
             return i;
@@ -88,18 +90,35 @@ template <int N_, int TPF_, int... Rs> struct Sched {
     }
 };
 
+// Two layouts for power-of-two schedules:
+//  * swizzle (threads holding <= 16 values): XOR the run index of the scatter into the bank bits.  Sub-pass x scatters
+//    runs of s_x consecutive elements at stride s_x R_x; the XOR puts the runs of one wave on distinct banks, and any
+//    32-aligned block of consecutive elements (what the gather reads) only sees a constant XOR: conflict-free both ways
+//    (measured: SQ_LDS_BANK_CONFLICT 43 % -> 0 of the LDS cycles).
+//  * linear (the 32-values-per-thread tiles): one padding slot per 32 elements; 2-4-way conflicts remain on some
+//    patterns, but every address is base + constant, which is what keeps those kernels from spilling.
+template <class S> constexpr bool lds_swizzled() { return S::all_pow2() && S::emax() <= 16; }
 template <class S, int X> MI_HD int lds_phys(int i) {
-    if constexpr (S::all_pow2()) {
+    if constexpr (lds_swizzled<S>()) {
         constexpr int ST = S::stride(X), SR = S::stride(X) * S::R[X];
         if constexpr (ST < 32)
             return i ^ (((i >> S::ilog2(SR)) << S::ilog2(ST)) & 31);
         else
             return i;
+    } else if constexpr (S::all_pow2()) {
+        return i + (i >> 5);
     } else if constexpr (S::paddiv() != 0) {
         return i + i / S::paddiv();
     } else {
         return i;
     }
+}
+// compile-time part of phys(base + k*step) - phys(base) when it is separable (see above); -1 when it is not
+template <class S> constexpr int lds_step_const(int k, int step, int span /* s_p R_p for scatters, 0 for gathers */) {
+    if (!S::all_pow2() || lds_swizzled<S>()) return -1;
+    if (step % 32 == 0) return k * (step + step / 32);
+    if (span != 0 && 32 % step == 0 && span % 32 == 0) return k * step + (k * step) / 32;
+    return -1;
 }
 
 template <Map M, int F, int TPF> MI_HD void map_tid(int tid, int& f, int& u) {
@@ -141,9 +160,15 @@ template <class T, class S, int P, int PART, class E> MI_HD void lds_scatter(con
         const int b = u + m * S::TPF;
         if ((m + 1) * S::TPF <= NB || b < NB) {
             const int base = (b / ST) * (ST * R) + (b % ST);
+            const int pbase = lds_phys<S, P>(base);
             static_for<0, R>([&](auto K_) {
                 constexpr int k = K_;
-                const int o = lds_phys<S, P>(base + k * ST);
+                constexpr int off = lds_step_const<S>(k, ST, ST * R);
+                int o;
+                if constexpr (off >= 0)
+                    o = pbase + off;
+                else
+                    o = lds_phys<S, P>(base + k * ST);
                 if constexpr (PART == 0)
                     ldsf[o] = v[m * R + k];
                 else if constexpr (PART == 1)
@@ -160,9 +185,15 @@ template <class T, class S, int P, int PART, class E> MI_HD void lds_gather(cx<T
         constexpr int m = M_;
         const int b = u + m * S::TPF;
         if ((m + 1) * S::TPF <= NB || b < NB) {
+            const int pbase = lds_phys<S, P - 1>(b);
             static_for<0, R>([&](auto K_) {
                 constexpr int k = K_;
-                const int o = lds_phys<S, P - 1>(b + k * NB);
+                constexpr int off = lds_step_const<S>(k, NB, 0);
+                int o;
+                if constexpr (off >= 0)
+                    o = pbase + off;
+                else
+                    o = lds_phys<S, P - 1>(b + k * NB);
                 if constexpr (PART == 0)
                     v[m * R + k] = ldsf[o];
                 else if constexpr (PART == 1)
@@ -182,7 +213,9 @@ template <class S, int P, Map MIN, Map MOUT> constexpr Map pass_map() {
 // X: executor. X::for_threads(fn(tid, cx<T>* v)) runs fn for every thread of the workgroup with that
 //    thread's private register array; X::barrier() is the workgroup barrier.
 // src(f, i) -> cx<T>: input element i of sequence f;   dst(f, i, value): output element i.
-template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, int PM, int P, class X, class SRC, class DST>
+// ABL (compile-time, tuning builds only): bit 2 skips the arithmetic, bit 3 skips the LDS exchange — ablation probes
+// that keep the HBM access pattern; production instantiations use ABL = 0.
+template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, int PM, int ABL, int P, class X, class SRC, class DST>
 MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& src, DST& dst) {
     constexpr int R = S::R[P], NB = S::nb(P), ST = S::stride(P), BPT = S::bpt(P);
     constexpr Map MP = pass_map<S, P, MIN, MOUT>();
@@ -191,7 +224,7 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
     ex.for_threads([&](int tid, cx<T>* v) {
         int f, u;
         map_tid<MP, F, S::TPF>(tid, f, u);
-        compute_pass<T, S, P>(v, u, tw);
+        if constexpr (!(ABL & 4)) compute_pass<T, S, P>(v, u, tw);
         if constexpr (LAST) {
             static_for<0, BPT>([&](auto M_) {
                 constexpr int m = M_;
@@ -204,13 +237,16 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
                     });
                 }
             });
+        } else if constexpr ((ABL & 8) != 0) {
         } else if constexpr (!SPLIT) {
             lds_scatter<T, S, P, 0>(v, u, (cx<T>*)lds_raw + f * S::template pitch_for<PM>());
         } else {
             lds_scatter<T, S, P, 1>(v, u, (T*)lds_raw + f * S::template pitch_for<PM>());
         }
     });
-    if constexpr (!LAST) {
+    if constexpr (!LAST && (ABL & 8) != 0) {
+        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, P + 1>(ex, lds_raw, tw, src, dst);
+    } else if constexpr (!LAST) {
         constexpr Map MQ = pass_map<S, P + 1, MIN, MOUT>();
         ex.barrier();
         if constexpr (!SPLIT) {
@@ -243,7 +279,7 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
             });
             ex.barrier();
         }
-        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, P + 1>(ex, lds_raw, tw, src, dst);
+        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, P + 1>(ex, lds_raw, tw, src, dst);
     }
 }
 
@@ -270,7 +306,7 @@ template <class T, class S, int F, bool SPLIT, int PM = 1> constexpr size_t lds_
 
 // SRC_IN_LDS: `src` reads the same LDS buffer the exchanges use (Rader/Bluestein second transform), so a
 // barrier separates the loads from the first scatter.
-template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, bool SRC_IN_LDS = false, int PM = 1, class X, class SRC, class DST>
+template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, bool SRC_IN_LDS = false, int PM = 1, int ABL = 0, class X, class SRC, class DST>
 MI_HD void wg_fft(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC src, DST dst) {
     static_assert(S::valid(), "radices must multiply to N");
     constexpr int R0 = S::R[0], NB0 = S::nb(0), BPT0 = S::bpt(0);
@@ -288,7 +324,7 @@ MI_HD void wg_fft(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC src, DS
         });
     });
     if constexpr (SRC_IN_LDS) ex.barrier();
-    wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, 0>(ex, lds_raw, tw, src, dst);
+    wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, 0>(ex, lds_raw, tw, src, dst);
 }
 
 }  // namespace mi355

@@ -54,7 +54,7 @@ constexpr int k2_pitch_mod(int f) { return f < 32 ? 32 / f : 1; }
 //     w^{c j} = w^{c b} * (w^{c nb})^k :
 // two two-level table look-ups (base and step) per butterfly, then step^(2^i) by squaring and each power
 // through at most log2(R) multiplications.  This replaces 2 R divergent table gathers per butterfly.
-template <class T, bool FIRST> struct K2Src {
+template <class T, bool FIRST, int ABL = 0> struct K2Src {
     const cx<T>* MI_RESTRICT in;
     long long M, b0, bmod0;
     T sgn_in;
@@ -79,8 +79,7 @@ template <class T, bool FIRST> struct K2Src {
             x.im *= sgn_in;
             v[k] = x;
         });
-        if constexpr (!FIRST) {
-            if (dbg & 1) return;  // measurement knob: skip the twiddles (wrong results)
+        if constexpr (!FIRST && !(ABL & 1)) {
             const unsigned c = (unsigned)(bmod0 + f);
             constexpr int LOG = (R > 16) ? 5 : (R > 8) ? 4 : (R > 4) ? 3 : (R > 2) ? 2 : (R > 1) ? 1 : 0;
             cx<T> sp[LOG > 0 ? LOG : 1];
@@ -98,7 +97,7 @@ template <class T, bool FIRST> struct K2Src {
     }
 };
 
-template <class T, class S, int F, bool FIRST, bool SPLIT, class X>
+template <class T, class S, int F, bool FIRST, bool SPLIT, int ABL = 0, class X>
 MI_HD void k2_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     constexpr int R = S::N;
     // XCD-aware tile order.  Workgroup b is dispatched to XCD b % 8 (MI355X_MICROARCH.md, observed, used
@@ -123,7 +122,7 @@ MI_HD void k2_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     const long long bdiv = FIRST ? 0 : (b0 / Sg);
     const long long bmod0 = FIRST ? 0 : (b0 % Sg);
     const unsigned obase = (unsigned)(bdiv * Sg * R + bmod0), s32 = (unsigned)Sg;
-    K2Src<T, FIRST> src{in, M, b0, bmod0, sgn_in, tlo, thi, hshift, lmask, p.dbg};
+    K2Src<T, FIRST, ABL> src{in, M, b0, bmod0, sgn_in, tlo, thi, hshift, lmask, p.dbg};
     auto dst = [=](int f, int k, cx<T> x) {
         x.im *= sgn_out;
         if constexpr (FIRST)
@@ -133,7 +132,7 @@ MI_HD void k2_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     };
     // first pass: lanes walk across the tile's columns on the way in and along each sequence on the way
     // out (the F*R output block is contiguous); later passes: across columns both ways
-    wg_fft<T, S, F, MAP_FF, FIRST ? MAP_EF : MAP_FF, SPLIT, false, k2_pitch_mod(F)>(ex, lds, p.tw, src, dst);
+    wg_fft<T, S, F, MAP_FF, FIRST ? MAP_EF : MAP_FF, SPLIT, false, k2_pitch_mod(F), ABL>(ex, lds, p.tw, src, dst);
 }
 
 // ---- Bluestein: any length n <= (M + 1) / 2 through two length-M workgroup transforms ---------------------

@@ -25,11 +25,11 @@ __global__ __launch_bounds__(F* S::TPF) void k1_kernel(K1Params<T> p) {
 }
 // two workgroups per CU is what keeps HBM busy while the other workgroup computes: ask the register
 // allocator for (2 * threads / 256) waves per SIMD
-template <class T, class S, int F, bool FIRST, bool SPLIT>
+template <class T, class S, int F, bool FIRST, bool SPLIT, int ABL = 0>
 __global__ __launch_bounds__(F* S::TPF, (F * S::TPF >= 512 ? 4 : 2)) void k2_kernel(K2Params<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevExec<T, regs_needed<S, SPLIT>()> ex;
-    k2_body<T, S, F, FIRST, SPLIT>(ex, p, (long long)blockIdx.x, smem);
+    k2_body<T, S, F, FIRST, SPLIT, ABL>(ex, p, (long long)blockIdx.x, smem);
 }
 
 template <class T, class S, int F, bool SPLIT> KernelEntry make_k1(int prec, const char* name) {
@@ -54,7 +54,7 @@ template <class T, class S, int F, bool SPLIT> KernelEntry make_k1(int prec, con
     };
     return e;
 }
-template <class T, class S, int F, bool FIRST, bool SPLIT> KernelEntry make_k2(int prec, const char* name) {
+template <class T, class S, int F, bool FIRST, bool SPLIT, int ABL = 0> KernelEntry make_k2(int prec, const char* name) {
     KernelEntry e{};
     e.kind = FIRST ? KIND_K2_FIRST : KIND_K2_LATER;
     e.prec = prec;
@@ -67,11 +67,11 @@ template <class T, class S, int F, bool FIRST, bool SPLIT> KernelEntry make_k2(i
     e.name = name;
     e.launch = [](const void* params, long long grid, void* stream) {
         void* args[] = {const_cast<void*>(params)};
-        (void)hipLaunchKernel((const void*)k2_kernel<T, S, F, FIRST, SPLIT>, dim3((unsigned)grid), dim3(F * S::TPF), args,
+        (void)hipLaunchKernel((const void*)k2_kernel<T, S, F, FIRST, SPLIT, ABL>, dim3((unsigned)grid), dim3(F * S::TPF), args,
                               lds_bytes<T, S, F, SPLIT, k2_pitch_mod(F)>(), (hipStream_t)stream);
     };
     e.prepare = []() -> int {
-        return (int)hipFuncSetAttribute((const void*)k2_kernel<T, S, F, FIRST, SPLIT>,
+        return (int)hipFuncSetAttribute((const void*)k2_kernel<T, S, F, FIRST, SPLIT, ABL>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<T, S, F, SPLIT, k2_pitch_mod(F)>());
     };
     return e;
@@ -234,7 +234,7 @@ template <class T, class S, int F, bool SPLIT> KernelEntry make_k1(int prec, con
     e.prepare = []() -> int { return 0; };
     return e;
 }
-template <class T, class S, int F, bool FIRST, bool SPLIT> KernelEntry make_k2(int prec, const char* name) {
+template <class T, class S, int F, bool FIRST, bool SPLIT, int ABL = 0> KernelEntry make_k2(int prec, const char* name) {
     KernelEntry e{};
     e.kind = FIRST ? KIND_K2_FIRST : KIND_K2_LATER;
     e.prec = prec;
@@ -249,7 +249,7 @@ template <class T, class S, int F, bool FIRST, bool SPLIT> KernelEntry make_k2(i
         std::vector<char> lds(lds_bytes<T, S, F, SPLIT, k2_pitch_mod(F)>() + 64, (char)0x5a);
         for (long long b = 0; b < grid; ++b) {
             HostExec<T, regs_needed<S, SPLIT>()> ex(F * S::TPF);
-            k2_body<T, S, F, FIRST, SPLIT>(ex, *(const K2Params<T>*)params, b, lds.data());
+            k2_body<T, S, F, FIRST, SPLIT, ABL>(ex, *(const K2Params<T>*)params, b, lds.data());
         }
     };
     e.prepare = []() -> int { return 0; };
@@ -357,11 +357,19 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
     reg.back().variant = V;                                                                                  \
     reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, false, SPLIT>(PREC, "k2later<" #__VA_ARGS__ ">xF" #F "v" #V)); \
     reg.back().variant = V
+#define MI_K2ABL(V, ABL, T, PREC, F, SPLIT, ...)                                                              \
+    reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, true, SPLIT, ABL>(PREC, "k2first<" #__VA_ARGS__ ">xF" #F "abl" #ABL));  \
+    reg.back().variant = V;                                                                                  \
+    reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, false, SPLIT, ABL>(PREC, "k2later<" #__VA_ARGS__ ">xF" #F "abl" #ABL)); \
+    reg.back().variant = V
 #define MI_K2(T, PREC, F, SPLIT, ...)                                                                  \
     reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, true, SPLIT>(PREC, "k2first<" #__VA_ARGS__ ">xF" #F)); \
     reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, false, SPLIT>(PREC, "k2later<" #__VA_ARGS__ ">xF" #F))
 
 #define MI_BS(T, PREC, F, ...) reg.push_back(make_bluestein<T, Sched<__VA_ARGS__>, F>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F))
 #define MI_RADER(T, PREC, F, ...) reg.push_back(make_rader<T, Sched<__VA_ARGS__>, F>(PREC, "rader<" #__VA_ARGS__ ">xF" #F))
+#define MI_RADERV(V, T, PREC, F, ...)                                                                   \
+    reg.push_back(make_rader<T, Sched<__VA_ARGS__>, F>(PREC, "rader<" #__VA_ARGS__ ">xF" #F "v" #V)); \
+    reg.back().variant = V
 
 }  // namespace mi355

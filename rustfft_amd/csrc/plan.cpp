@@ -310,6 +310,7 @@ static bool choose_macro_radices(int prec, size_t n, std::vector<size_t>& out) {
     }
     if (best.empty()) return false;
     out = best;
+    if (env_int("MI355FFT_ORDER") == 1) std::reverse(out.begin(), out.end());  // tuning: smallest radix first
     return true;
 }
 
@@ -369,8 +370,12 @@ template <class T> static int build_plan_t(Plan& plan) {
         return MI355FFT_OK;
     }
     // prime length with a compiled Rader body (raders_algorithm.rs:65-124 precomputation, in f64)
-    for (auto& e : registry()) {
-        if (e.kind != KIND_RADER || e.prec != plan.prec || (size_t)e.aux != n) continue;
+    for (auto& e0 : registry()) {
+        if (e0.kind != KIND_RADER || e0.prec != plan.prec || (size_t)e0.aux != n || e0.variant != 0) continue;
+        const KernelEntry* chosen = &e0;
+        for (auto& ev : registry())  // tuning: MI355FFT_VARIANT selects an alternative tiling of the same prime
+            if (ev.kind == KIND_RADER && ev.prec == plan.prec && ev.aux == e0.aux && ev.variant == env_int("MI355FFT_VARIANT")) chosen = &ev;
+        const KernelEntry& e = *chosen;
         if (e.prepare()) return MI355FFT_ERR_HIP;
         const uint64_t pp = n, g = primitive_root(pp), ginv = modpow(g, pp - 2, pp);
         std::vector<cd> d(pp - 1);
