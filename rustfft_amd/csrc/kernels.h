@@ -20,7 +20,7 @@
 
 namespace mi355 {
 
-template <class T, class S, int F, bool SPLIT, class X>
+template <class T, class S, int F, bool SPLIT, int ABL = 0, class X>
 MI_HD void k1_body(X& ex, const K1Params<T>& p, long long block, void* lds) {
     const long long fft0 = block * F;
     // workgroup-uniform base + 32-bit element offsets (F * N < 2^31): one address VGPR per access
@@ -30,7 +30,11 @@ MI_HD void k1_body(X& ex, const K1Params<T>& p, long long block, void* lds) {
     const T sgn = p.sgn;
     auto src = [=](int f, int i) -> cx<T> {
         if (f < rows) {
-            cx<T> x = in[(unsigned)(f * S::N + i)];
+            cx<T> x;
+            if constexpr ((ABL & 16) != 0)
+                x = ld_nt(in + (unsigned)(f * S::N + i));
+            else
+                x = in[(unsigned)(f * S::N + i)];
             x.im *= sgn;
             return x;
         }
@@ -39,10 +43,13 @@ MI_HD void k1_body(X& ex, const K1Params<T>& p, long long block, void* lds) {
     auto dst = [=](int f, int i, cx<T> x) {
         if (f < rows) {
             x.im *= sgn;
-            out[(unsigned)(f * S::N + i)] = x;
+            if constexpr ((ABL & 32) != 0)
+                st_nt(out + (unsigned)(f * S::N + i), x);
+            else
+                out[(unsigned)(f * S::N + i)] = x;
         }
     };
-    wg_fft<T, S, F, MAP_EF, MAP_EF, SPLIT>(ex, lds, p.tw, elem_src(src), dst);
+    wg_fft<T, S, F, MAP_EF, MAP_EF, SPLIT, false, 1, (ABL & 15)>(ex, lds, p.tw, elem_src(src), dst);
 }
 
 // LDS pitch residue for a tile of F columns: lanes walk across the columns first, so the (32 / F) row slots of one
@@ -75,7 +82,11 @@ template <class T, bool FIRST, int ABL = 0> struct K2Src {
         const unsigned col = (unsigned)(b0 + f), m32 = (unsigned)M;
         static_for<0, R>([&](auto K_) {
             constexpr int k = K_;
-            cx<T> x = in[col + (unsigned)(b + k * nb) * m32];
+            cx<T> x;
+            if constexpr ((ABL & 16) != 0)
+                x = ld_nt(in + (col + (unsigned)(b + k * nb) * m32));
+            else
+                x = in[col + (unsigned)(b + k * nb) * m32];
             x.im *= sgn_in;
             v[k] = x;
         });
@@ -125,14 +136,15 @@ MI_HD void k2_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     K2Src<T, FIRST, ABL> src{in, M, b0, bmod0, sgn_in, tlo, thi, hshift, lmask, p.dbg};
     auto dst = [=](int f, int k, cx<T> x) {
         x.im *= sgn_out;
-        if constexpr (FIRST)
-            out[(unsigned)(b0 + f) * (unsigned)R + (unsigned)k] = x;
+        cx<T>* o = FIRST ? out + ((unsigned)(b0 + f) * (unsigned)R + (unsigned)k) : out + (obase + (unsigned)f + (unsigned)k * s32);
+        if constexpr ((ABL & 32) != 0)
+            st_nt(o, x);
         else
-            out[obase + (unsigned)f + (unsigned)k * s32] = x;
+            *o = x;
     };
     // first pass: lanes walk across the tile's columns on the way in and along each sequence on the way
     // out (the F*R output block is contiguous); later passes: across columns both ways
-    wg_fft<T, S, F, MAP_FF, FIRST ? MAP_EF : MAP_FF, SPLIT, false, k2_pitch_mod(F), ABL>(ex, lds, p.tw, src, dst);
+    wg_fft<T, S, F, MAP_FF, FIRST ? MAP_EF : MAP_FF, SPLIT, false, k2_pitch_mod(F), (ABL & 15)>(ex, lds, p.tw, src, dst);
 }
 
 // ---- Bluestein: any length n <= (M + 1) / 2 through two length-M workgroup transforms ---------------------

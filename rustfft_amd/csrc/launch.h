@@ -17,11 +17,11 @@ template <class T, int NREG> struct DevExec {
     __device__ __forceinline__ void barrier() { __syncthreads(); }
 };
 
-template <class T, class S, int F, bool SPLIT>
+template <class T, class S, int F, bool SPLIT, int ABL = 0>
 __global__ __launch_bounds__(F* S::TPF) void k1_kernel(K1Params<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevExec<T, regs_needed<S, SPLIT>()> ex;
-    k1_body<T, S, F, SPLIT>(ex, p, (long long)blockIdx.x, smem);
+    k1_body<T, S, F, SPLIT, ABL>(ex, p, (long long)blockIdx.x, smem);
 }
 // two workgroups per CU is what keeps HBM busy while the other workgroup computes: ask the register
 // allocator for (2 * threads / 256) waves per SIMD
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(F* S::TPF, (F * S::TPF >= 512 ? 4 : 2)) void k2_ker
     k2_body<T, S, F, FIRST, SPLIT, ABL>(ex, p, (long long)blockIdx.x, smem);
 }
 
-template <class T, class S, int F, bool SPLIT> KernelEntry make_k1(int prec, const char* name) {
+template <class T, class S, int F, bool SPLIT, int ABL = 0> KernelEntry make_k1(int prec, const char* name) {
     KernelEntry e{};
     e.kind = KIND_K1;
     e.prec = prec;
@@ -45,11 +45,11 @@ template <class T, class S, int F, bool SPLIT> KernelEntry make_k1(int prec, con
     e.name = name;
     e.launch = [](const void* params, long long grid, void* stream) {
         void* args[] = {const_cast<void*>(params)};
-        (void)hipLaunchKernel((const void*)k1_kernel<T, S, F, SPLIT>, dim3((unsigned)grid), dim3(F * S::TPF), args,
+        (void)hipLaunchKernel((const void*)k1_kernel<T, S, F, SPLIT, ABL>, dim3((unsigned)grid), dim3(F * S::TPF), args,
                               lds_bytes<T, S, F, SPLIT>(), (hipStream_t)stream);
     };
     e.prepare = []() -> int {
-        return (int)hipFuncSetAttribute((const void*)k1_kernel<T, S, F, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        return (int)hipFuncSetAttribute((const void*)k1_kernel<T, S, F, SPLIT, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds_bytes<T, S, F, SPLIT>());
     };
     return e;
@@ -213,7 +213,7 @@ template <class T, int NREG> struct HostExec {
     }
     void barrier() {}
 };
-template <class T, class S, int F, bool SPLIT> KernelEntry make_k1(int prec, const char* name) {
+template <class T, class S, int F, bool SPLIT, int ABL = 0> KernelEntry make_k1(int prec, const char* name) {
     KernelEntry e{};
     e.kind = KIND_K1;
     e.prec = prec;
@@ -228,7 +228,7 @@ template <class T, class S, int F, bool SPLIT> KernelEntry make_k1(int prec, con
         std::vector<char> lds(lds_bytes<T, S, F, SPLIT>() + 64, (char)0x5a);  // poisoned LDS
         for (long long b = 0; b < grid; ++b) {
             HostExec<T, regs_needed<S, SPLIT>()> ex(F * S::TPF);
-            k1_body<T, S, F, SPLIT>(ex, *(const K1Params<T>*)params, b, lds.data());
+            k1_body<T, S, F, SPLIT, ABL>(ex, *(const K1Params<T>*)params, b, lds.data());
         }
     };
     e.prepare = []() -> int { return 0; };
@@ -351,6 +351,12 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
 }
 #endif
 
+#define MI_K1ABL(V, ABL, T, PREC, F, SPLIT, ...)                                                               \
+    reg.push_back(make_k1<T, Sched<__VA_ARGS__>, F, SPLIT, ABL>(PREC, "k1<" #__VA_ARGS__ ">xF" #F "abl" #ABL)); \
+    reg.back().variant = V
+#define MI_K1V(V, T, PREC, F, SPLIT, ...)                                                       \
+    reg.push_back(make_k1<T, Sched<__VA_ARGS__>, F, SPLIT>(PREC, "k1<" #__VA_ARGS__ ">xF" #F "v" #V)); \
+    reg.back().variant = V
 #define MI_K1(T, PREC, F, SPLIT, ...) reg.push_back(make_k1<T, Sched<__VA_ARGS__>, F, SPLIT>(PREC, "k1<" #__VA_ARGS__ ">xF" #F))
 #define MI_K2V(V, T, PREC, F, SPLIT, ...)                                                                   \
     reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, true, SPLIT>(PREC, "k2first<" #__VA_ARGS__ ">xF" #F "v" #V));  \

@@ -12,6 +12,24 @@ template <class V, int E, int NT> __global__ __launch_bounds__(NT) void blockcop
 #pragma unroll
     for (int k = 0; k < E; ++k) out[base + threadIdx.x + k * NT] = v[k];
 }
+template <class V, int E, int NT, int NTL, int NTS> __global__ __launch_bounds__(NT) void blockcopy_nt(const V* __restrict__ in, V* __restrict__ out) {
+    const size_t base = (size_t)blockIdx.x * (E * NT);
+    V v[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        if (NTL)
+            v[k] = __builtin_nontemporal_load(&in[base + threadIdx.x + k * NT]);
+        else
+            v[k] = in[base + threadIdx.x + k * NT];
+    }
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        if (NTS)
+            __builtin_nontemporal_store(v[k], &out[base + threadIdx.x + k * NT]);
+        else
+            out[base + threadIdx.x + k * NT] = v[k];
+    }
+}
 // column-tile read (rows of F contiguous elements, row stride M elements), contiguous write (K2 first-pass shape)
 template <class V, int F, int R, int NT> __global__ __launch_bounds__(NT) void tilecopy(const V* __restrict__ in, V* __restrict__ out, size_t M, int strided_out) {
     constexpr int E = F * R / NT;
@@ -84,6 +102,12 @@ int main() {
     report("blockcopy float4 x16 /256thr in-place", time_it([&] { blockcopy<float4, 16, 256><<<bytes / 16 / 4096, 256>>>((float4*)a, (float4*)a); }));
     report("blockcopy float4 x4 /256thr (a->b)", time_it([&] { blockcopy<float4, 4, 256><<<bytes / 16 / 1024, 256>>>((float4*)a, (float4*)b); }));
     report("blockcopy float2 x4 /256thr (a->b)", time_it([&] { blockcopy<float2, 4, 256><<<bytes / 8 / 1024, 256>>>((float2*)a, (float2*)b); }));
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    report("blockcopy v2 x16 nt-load", time_it([&] { blockcopy_nt<v2, 16, 256, 1, 0><<<bytes / 8 / 4096, 256>>>((v2*)a, (v2*)b); }));
+    report("blockcopy v2 x16 nt-store", time_it([&] { blockcopy_nt<v2, 16, 256, 0, 1><<<bytes / 8 / 4096, 256>>>((v2*)a, (v2*)b); }));
+    report("blockcopy v2 x16 nt-load+store", time_it([&] { blockcopy_nt<v2, 16, 256, 1, 1><<<bytes / 8 / 4096, 256>>>((v2*)a, (v2*)b); }));
+    report("blockcopy v2 x16 nt-load+store in-place", time_it([&] { blockcopy_nt<v2, 16, 256, 1, 1><<<bytes / 8 / 4096, 256>>>((v2*)a, (v2*)a); }));
+    report("blockcopy v2 x16 plain (ref)", time_it([&] { blockcopy_nt<v2, 16, 256, 0, 0><<<bytes / 8 / 4096, 256>>>((v2*)a, (v2*)b); }));
     const size_t n = (size_t)1 << 20, batch = bytes / 8 / n;
     report("tile 1024x16 float2 rd-strided wr-contig", time_it([&] { tilecopy<float2, 16, 1024, 1024><<<batch * (1024 / 16), 1024>>>((float2*)a, (float2*)b, 1024, 0); }));
     report("tile 1024x16 float2 rd-strided wr-strided", time_it([&] { tilecopy<float2, 16, 1024, 1024><<<batch * (1024 / 16), 1024>>>((float2*)a, (float2*)b, 1024, 1); }));
