@@ -49,9 +49,10 @@ def test_multi_pass_sizes_all_api_modes(emu_planner, oracle, dtype):
 
 
 def test_config2_and_three_pass_shapes(emu_planner, oracle):
-    """BASELINE config 2 (N = 2^20, f32, forward + inverse) and config 5's N = 2^22, small batch."""
+    """BASELINE config 2 (N = 2^20, f32, forward + inverse), config 5's N = 2^22 (two passes of 2048-row tiles) and a
+    three-pass length (2^23), small batch."""
     planner = emu_planner(np.complex64)
-    for n, batch in ((1 << 20, 2), (1 << 22, 1)):
+    for n, batch in ((1 << 20, 2), (1 << 22, 1), (1 << 23, 1)):
         x = zero_mean_signal(n * batch, np.complex64)
         fwd, inv = planner.plan_fft_forward(n), planner.plan_fft_inverse(n)
         y = x.copy()
@@ -62,7 +63,8 @@ def test_config2_and_three_pass_shapes(emu_planner, oracle):
         assert rel_l2(y, numpy_fft(x, n, False)) < 2e-6
         inv.process(y)  # round trip: ifft(fft(x)) == N x
         assert rel_l2(y / n, x) < 2e-6
-    assert planner.plan_fft_forward(1 << 22).describe().count("k2") == 3
+    assert planner.plan_fft_forward(1 << 22).describe().count("k2") == 2  # 2048 x 2048
+    assert planner.plan_fft_forward(1 << 23).describe().count("k2") == 3
 
 
 def test_chunked_workspace_matches_unchunked(emu_planner):
