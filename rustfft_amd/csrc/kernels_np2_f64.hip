@@ -6,9 +6,8 @@ namespace mi355 {
 void register_np2_f64(std::vector<KernelEntry>& reg) {
     MI_K1(double, 64, 2, false, 1200, 120, 10, 10, 12);
     MI_RADER(double, 64, 4, 1008, 144, 16, 9, 7);  // four rows per workgroup measured 37 % faster than two in f64
-    MI_RADERV(1, double, 64, 4, 1008, 63, 16, 9, 7);  // tuning: one wave per row, up to 21 values per thread
-    MI_RADERV(2, double, 64, 2, 1008, 63, 16, 9, 7);
-    MI_RADERV(3, double, 64, 2, 1008, 144, 16, 9, 7);
+    MI_RADERV(1, double, 64, 2, 1008, 144, 16, 9, 7);
+    MI_RADERV(2, double, 64, 1, 1008, 144, 16, 9, 7);
     MI_BS_LIST(double, 64);
     reg.push_back(make_pointwise<double>(64));
     reg.push_back(make_dyn_k1<double>(64));
