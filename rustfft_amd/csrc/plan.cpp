@@ -81,6 +81,9 @@ template <class T> static std::vector<T> build_subpass_twiddles(const KernelEntr
 }
 
 Plan::~Plan() {
+    // asynchronous launches may still be reading the tables / workspace: drain the streams this plan was used on
+    for (auto& kv : workspaces) backend::sync(kv.first);
+    backend::sync(nullptr);
     for (void* p : device_allocs) backend::dfree(p);
     for (auto& kv : workspaces) backend::dfree(kv.second.ptr);
 }

@@ -321,3 +321,24 @@ def test_runtime_scheduled_kernels(planners, oracle, dtype):
             assert ("dyn_k1" if p <= 13 else "dyn_rader") in fft.describe()  # 5..13 are compiled radices themselves
             check_fft_algorithm(fft, p, d, reference=oracle.plan(dtype, p, d), n=3)
     del os.environ["MI355FFT_DYN_RADER"]
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_random_lengths_vs_float64(planners, dtype):
+    """Fuzz over the planner: 150 random lengths in [2, 300000] (every plan kind: single kernel, multi-pass, run-time
+    scheduled mixed radix, Rader, one-kernel and multi-kernel Bluestein) with random ragged batches, forward and inverse,
+    against numpy.fft in complex128."""
+    rng = np.random.default_rng(20260924)
+    planner = planners[np.dtype(dtype)]
+    lengths = sorted(set(int(v) for v in np.exp(rng.uniform(np.log(2), np.log(300000), 150))) | {8192, 1 << 16, 1 << 17, 1009})
+    seen = set()
+    for n in lengths:
+        batch = int(rng.integers(1, max(2, min(40, 400000 // n))))
+        d = int(rng.integers(0, 2))
+        fft = planner.plan_fft(n, d)
+        seen.add(fft.describe().split("<")[0].split("(")[0])
+        x = zero_mean_signal(n * batch, dtype, seed=n)
+        y = x.copy()
+        fft.process(y)
+        assert rel_l2(y, numpy_fft(x, n, d == 1)) < REL[np.dtype(dtype)], (n, batch, d, fft.describe())
+    assert {"k1", "k2first", "dyn_k1", "rader", "bluestein", "bluestein_large"} <= seen, seen
