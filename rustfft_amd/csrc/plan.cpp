@@ -34,6 +34,14 @@ void ensure_registry() {
         register_k2_f64(r);
         register_np2_f32(r);
         register_np2_f64(r);
+        register_smooth_f32_0(r);
+        register_smooth_f32_1(r);
+        register_smooth_f32_2(r);
+        register_smooth_f32_3(r);
+        register_smooth_f64_0(r);
+        register_smooth_f64_1(r);
+        register_smooth_f64_2(r);
+        register_smooth_f64_3(r);
     });
 }
 

@@ -36,6 +36,15 @@ void register_k2_f32(std::vector<KernelEntry>&);
 void register_k2_f64(std::vector<KernelEntry>&);
 void register_np2_f32(std::vector<KernelEntry>&);  // non-power-of-two: mixed radix, Rader, Bluestein
 void register_np2_f64(std::vector<KernelEntry>&);
+// generated: compiled schedules for the 7-smooth lengths in (16, 4096] (tools/gen_smooth_kernels.py)
+void register_smooth_f32_0(std::vector<KernelEntry>&);
+void register_smooth_f32_1(std::vector<KernelEntry>&);
+void register_smooth_f32_2(std::vector<KernelEntry>&);
+void register_smooth_f32_3(std::vector<KernelEntry>&);
+void register_smooth_f64_0(std::vector<KernelEntry>&);
+void register_smooth_f64_1(std::vector<KernelEntry>&);
+void register_smooth_f64_2(std::vector<KernelEntry>&);
+void register_smooth_f64_3(std::vector<KernelEntry>&);
 
 template <class S> inline void fill_sched(KernelEntry& e) {
     e.tpf = S::TPF;

@@ -192,8 +192,7 @@ def test_runtime_scheduled_kernels(emu_planner, oracle, dtype):
     src/algorithm/radixn.rs:497-541 covers factors 2..7 over small bases; here every compiled radix appears) and
     primes with 13-smooth p - 1 through the run-time scheduled Rader (raders_algorithm.rs:302-309: primes < 100)."""
     planner = emu_planner(dtype)
-    smooth = [3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 18, 20, 21, 22, 24, 26, 27, 33, 35, 39, 45, 48, 49, 55, 60, 63, 65, 77, 80,
-              81, 91, 96, 100, 120, 121, 125, 143, 144, 169, 210, 243, 343, 360, 625, 720, 1000, 1001, 1331, 2187, 2310, 3000, 4095]
+    smooth = [3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 22, 26, 33, 39, 55, 65, 77, 91, 121, 143, 169, 1001, 1331, 2310, 4095, 5000]
     for n in smooth:
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
@@ -210,3 +209,26 @@ def test_runtime_scheduled_kernels(emu_planner, oracle, dtype):
             check_fft_algorithm(fft, p, d, reference=oracle.plan(dtype, p, d), n=3)
     assert "dyn_rader" in planner.plan_fft(1201, 0).describe() and "dyn_rader" in planner.plan_fft(97, 0).describe()
     del os.environ["MI355FFT_DYN_RADER"]
+
+
+def _seven_smooth(limit):
+    s = {1}
+    for p in (2, 3, 5, 7):
+        s = {v * p**k for v in s for k in range(0, 13) if v * p**k <= limit}
+    return sorted(v for v in s if v > 16 and (v & (v - 1)))
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_compiled_smooth_schedules(emu_planner, dtype):
+    """Every 7-smooth length in (16, 4096] has its own compiled schedule (tools/gen_smooth_kernels.py — the lengths the
+    reference plans as RadixN, src/plan.rs:508-607): forward and inverse, ragged batch, vs numpy in float64."""
+    planner = emu_planner(dtype)
+    tol = 1e-6 if dtype == np.complex64 else 1e-14
+    for n in _seven_smooth(4096):
+        for d in (0, 1):
+            fft = planner.plan_fft(n, d)
+            assert fft.describe().startswith("k1<%d," % n), (n, fft.describe())
+        x = zero_mean_signal(n * 3, dtype, seed=n)
+        y = x.copy()
+        planner.plan_fft(n, n % 2).process(y)
+        assert rel_l2(y, numpy_fft(x, n, n % 2 == 1)) < tol, n
