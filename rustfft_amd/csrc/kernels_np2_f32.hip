@@ -9,6 +9,7 @@ void register_np2_f32(std::vector<KernelEntry>& reg) {
     MI_RADERV(1, float, 32, 2, 1008, 144, 16, 9, 7);
     MI_RADERV(2, float, 32, 2, 1008, 63, 16, 9, 7);  // tuning: one wave per row, up to 21 values per thread (slower)
     MI_BS_LIST(float, 32);
+    MI_BS_LIST3_F32(float, 32);
     reg.push_back(make_pointwise<float>(32));
     reg.push_back(make_dyn_k1<float>(32));
     reg.push_back(make_dyn_rader<float>(32));

@@ -162,7 +162,7 @@ def test_baseline_configs_3_and_4(emu_planner, oracle, dtype):
     """Config 3: N = 1200 (native mixed radix 10 x 10 x 12); config 4: N = 1009 (Rader over 16 x 9 x 7) and its
     Bluestein companion 1019 (M = 2048): all four API modes, ragged batch (tail workgroup partially filled)."""
     planner = emu_planner(dtype)
-    for n, tag in ((1200, "k1<1200"), (1009, "rader<1008"), (1019, "bluestein<2048"), (719, "bluestein<2048")):
+    for n, tag in ((1200, "k1<1200"), (1009, "rader<1008"), (1019, "bluestein<2048"), (719, "bluestein<1536")):
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
             assert tag in fft.describe(), fft.describe()
