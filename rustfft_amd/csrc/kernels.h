@@ -147,6 +147,74 @@ MI_HD void k2_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     wg_fft<T, S, F, MAP_FF, FIRST ? MAP_EF : MAP_FF, SPLIT, false, k2_pitch_mod(F), (ABL & 15)>(ex, lds, p.tw, src, dst);
 }
 
+// ---- large-N pass for lengths that are not powers of two ------------------------------------------------------------
+// Same law as k2_body with the two alignment assumptions removed: the last tile of a transform may be ragged (M need
+// not be a multiple of F: columns >= M are masked) and a tile may straddle a multiple of S (B div S and B mod S are
+// taken per column).  This is the GPU form of the reference's generic MixedRadix (src/algorithm/mixed_radix.rs:128-158)
+// for composite lengths; the power-of-two plans keep the specialised body above.
+template <class T, bool FIRST> struct K2gSrc {
+    const cx<T>* MI_RESTRICT in;
+    unsigned M, S, b0;
+    T sgn_in;
+    const cx<T>* MI_RESTRICT tlo;
+    const cx<T>* MI_RESTRICT thi;
+    int hshift, lmask;
+    MI_HD cx<T> lut(unsigned e) const { return tlo[e & (unsigned)lmask] * thi[e >> hshift]; }
+    template <int R, int LOG, int K, int J0> MI_HD static void apply_tw(cx<T>* v, cx<T> w, const cx<T>* sp) {
+        v[K] = v[K] * w;
+        static_for<J0, LOG>([&](auto J_) {
+            constexpr int j = J_;
+            if constexpr (K + (1 << j) < R) apply_tw<R, LOG, K + (1 << j), j + 1>(v, w * sp[j], sp);
+        });
+    }
+    template <int R, class TT> MI_HD void bfly(int f, int b, int nb, cx<TT>* v) const {
+        const unsigned B = b0 + (unsigned)f;
+        const unsigned col = B < M ? B : 0;  // masked columns read column 0 (never stored)
+        static_for<0, R>([&](auto K_) {
+            constexpr int k = K_;
+            cx<T> x = in[col + (unsigned)(b + k * nb) * M];
+            x.im *= sgn_in;
+            v[k] = x;
+        });
+        if constexpr (!FIRST) {
+            const unsigned c = col % S;
+            constexpr int LOG = (R > 16) ? 5 : (R > 8) ? 4 : (R > 4) ? 3 : (R > 2) ? 2 : (R > 1) ? 1 : 0;
+            cx<T> sp[LOG > 0 ? LOG : 1];
+            if constexpr (LOG > 0) {
+                sp[0] = lut(c * (unsigned)nb);
+                static_for<1, LOG>([&](auto I_) {
+                    constexpr int i = I_;
+                    sp[i] = sp[i - 1] * sp[i - 1];
+                });
+            }
+            apply_tw<R, LOG, 0, 0>(v, lut(c * (unsigned)b), sp);
+        }
+    }
+};
+
+template <class T, class S, int F, bool FIRST, class X>
+MI_HD void k2g_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
+    constexpr int R = S::N;
+    const long long g = block / p.tiles_per_fft;
+    const unsigned b0 = (unsigned)(block % p.tiles_per_fft) * (unsigned)F;
+    const cx<T>* MI_RESTRICT in = p.in + g * p.n;
+    cx<T>* MI_RESTRICT out = p.out + g * p.n;
+    const unsigned M = (unsigned)p.m, Sg = (unsigned)p.s;
+    const T sgn_out = p.sgn_out;
+    K2gSrc<T, FIRST> src{in, M, Sg, b0, p.sgn_in, p.tlo, p.thi, p.hshift, p.lmask};
+    auto dst = [=](int f, int k, cx<T> x) {
+        const unsigned B = b0 + (unsigned)f;
+        if (B < M) {
+            x.im *= sgn_out;
+            if constexpr (FIRST)
+                out[B * (unsigned)R + (unsigned)k] = x;
+            else
+                out[(B / Sg) * (Sg * (unsigned)R) + (B % Sg) + (unsigned)k * Sg] = x;
+        }
+    };
+    wg_fft<T, S, F, MAP_FF, FIRST ? MAP_EF : MAP_FF, false, false, k2_pitch_mod(F)>(ex, lds, p.tw, src, dst);
+}
+
 // ---- Bluestein: any length n <= (M + 1) / 2 through two length-M workgroup transforms ---------------------
 template <class T, class S, int F, class X>
 MI_HD void bluestein_body(X& ex, const BluesteinParams<T>& p, long long block, void* lds) {

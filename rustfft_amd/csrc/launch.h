@@ -152,6 +152,33 @@ template <class T, class S, int F> KernelEntry make_rader(int prec, const char* 
     };
     return e;
 }
+template <class T, class S, int F, bool FIRST>
+__global__ __launch_bounds__(F* S::TPF) void k2g_kernel(K2Params<T> p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevExec<T, regs_needed<S, false>()> ex;
+    k2g_body<T, S, F, FIRST>(ex, p, (long long)blockIdx.x, smem);
+}
+template <class T, class S, int F, bool FIRST> KernelEntry make_k2g(int prec, const char* name) {
+    KernelEntry e{};
+    e.kind = FIRST ? KIND_K2G_FIRST : KIND_K2G_LATER;
+    e.prec = prec;
+    e.n = S::N;
+    e.f = F;
+    fill_sched<S>(e);
+    e.threads = F * S::TPF;
+    e.lds_bytes = lds_bytes<T, S, F, false, k2_pitch_mod(F)>();
+    e.name = name;
+    e.launch = [](const void* params, long long grid, void* stream) {
+        void* args[] = {const_cast<void*>(params)};
+        (void)hipLaunchKernel((const void*)k2g_kernel<T, S, F, FIRST>, dim3((unsigned)grid), dim3(F * S::TPF), args,
+                              lds_bytes<T, S, F, false, k2_pitch_mod(F)>(), (hipStream_t)stream);
+    };
+    e.prepare = []() -> int {
+        return (int)hipFuncSetAttribute((const void*)k2g_kernel<T, S, F, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds_bytes<T, S, F, false, k2_pitch_mod(F)>());
+    };
+    return e;
+}
 constexpr int kDynEmax = 16, kDynEmaxLight = 12;
 template <class T, bool LIGHT> __global__ __launch_bounds__(512) void dyn_k1_kernel(DynK1Params<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -310,6 +337,26 @@ template <class T, class S, int F> KernelEntry make_rader(int prec, const char* 
     e.prepare = []() -> int { return 0; };
     return e;
 }
+template <class T, class S, int F, bool FIRST> KernelEntry make_k2g(int prec, const char* name) {
+    KernelEntry e{};
+    e.kind = FIRST ? KIND_K2G_FIRST : KIND_K2G_LATER;
+    e.prec = prec;
+    e.n = S::N;
+    e.f = F;
+    fill_sched<S>(e);
+    e.threads = F * S::TPF;
+    e.lds_bytes = lds_bytes<T, S, F, false, k2_pitch_mod(F)>();
+    e.name = name;
+    e.launch = [](const void* params, long long grid, void*) {
+        std::vector<char> lds(lds_bytes<T, S, F, false, k2_pitch_mod(F)>() + 64, (char)0x5a);
+        for (long long b = 0; b < grid; ++b) {
+            HostExec<T, regs_needed<S, false>()> ex(F * S::TPF);
+            k2g_body<T, S, F, FIRST>(ex, *(const K2Params<T>*)params, b, lds.data());
+        }
+    };
+    e.prepare = []() -> int { return 0; };
+    return e;
+}
 constexpr int kDynEmax = 16, kDynEmaxLight = 12;
 template <class T> KernelEntry make_dyn_k1(int prec) {
     KernelEntry e{};
@@ -372,6 +419,9 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
     reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, true, SPLIT>(PREC, "k2first<" #__VA_ARGS__ ">xF" #F)); \
     reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, false, SPLIT>(PREC, "k2later<" #__VA_ARGS__ ">xF" #F))
 
+#define MI_K2G(T, PREC, F, ...)                                                                        \
+    reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, true>(PREC, "k2gfirst<" #__VA_ARGS__ ">xF" #F));  \
+    reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, false>(PREC, "k2glater<" #__VA_ARGS__ ">xF" #F))
 #define MI_BS(T, PREC, F, ...) reg.push_back(make_bluestein<T, Sched<__VA_ARGS__>, F>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F))
 #define MI_RADER(T, PREC, F, ...) reg.push_back(make_rader<T, Sched<__VA_ARGS__>, F>(PREC, "rader<" #__VA_ARGS__ ">xF" #F))
 #define MI_RADERV(V, T, PREC, F, ...)                                                                   \

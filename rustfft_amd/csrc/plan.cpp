@@ -34,6 +34,14 @@ void ensure_registry() {
         register_k2_f64(r);
         register_np2_f32(r);
         register_np2_f64(r);
+        register_k2g_f32_0(r);
+        register_k2g_f32_1(r);
+        register_k2g_f32_2(r);
+        register_k2g_f32_3(r);
+        register_k2g_f64_0(r);
+        register_k2g_f64_1(r);
+        register_k2g_f64_2(r);
+        register_k2g_f64_3(r);
         register_smooth_f32_0(r);
         register_smooth_f32_1(r);
         register_smooth_f32_2(r);
@@ -325,6 +333,41 @@ static bool choose_macro_radices(int prec, size_t n, std::vector<size_t>& out) {
     return true;
 }
 
+// radices for a composite length that is not a power of two: tile heights with a compiled general pass kernel
+// (k2g_body), fewest passes, then the most balanced split
+static bool choose_general_radices(int prec, size_t n, std::vector<size_t>& out) {
+    std::vector<size_t> avail;
+    for (auto& e : registry())
+        if (e.kind == KIND_K2G_FIRST && e.prec == prec) avail.push_back(e.n);
+    std::sort(avail.begin(), avail.end(), std::greater<size_t>());
+    std::vector<size_t> best, cur;
+    size_t best_max = 0;
+    for (int P = 2; P <= 4 && best.empty(); ++P) {
+        struct Rec {
+            static void go(const std::vector<size_t>& av, size_t start, size_t rem, int left, std::vector<size_t>& cur,
+                           std::vector<size_t>& best, size_t& best_max) {
+                if (left == 0) {
+                    if (rem == 1 && (best.empty() || cur.front() < best_max)) {
+                        best = cur;
+                        best_max = cur.front();
+                    }
+                    return;
+                }
+                for (size_t i = start; i < av.size(); ++i) {
+                    if (rem % av[i]) continue;
+                    cur.push_back(av[i]);
+                    go(av, i, rem / av[i], left - 1, cur, best, best_max);
+                    cur.pop_back();
+                }
+            }
+        };
+        Rec::go(avail, 0, n, P, cur, best, best_max);
+    }
+    if (best.empty()) return false;
+    out = best;
+    return true;
+}
+
 template <class T> static int build_plan_t(Plan& plan) {
     const size_t n = plan.len;
     if (n <= 1) {
@@ -361,6 +404,40 @@ template <class T> static int build_plan_t(Plan& plan) {
             if (rc) return rc;
             if (p > 0) {
                 // two-level table for w_Q^e, Q = S R, e < Q:  e = (e >> h) << h | (e & mask)
+                const size_t Q = s * R;
+                int bits = 0;
+                while (((size_t)1 << bits) < Q) ++bits;
+                const int h = (bits + 1) / 2;
+                std::vector<T> lo, hi;
+                for (size_t e = 0; e < ((size_t)1 << h); ++e) push_tw<T>(lo, e, Q);
+                for (size_t q = 0; q <= ((Q - 1) >> h); ++q) push_tw<T>(hi, q << h, Q);
+                pd.hshift = h;
+                pd.lmask = (int)(((size_t)1 << h) - 1);
+                pd.d_tlo = upload<T>(plan, lo, &rc);
+                if (rc) return rc;
+                pd.d_thi = upload<T>(plan, hi, &rc);
+                if (rc) return rc;
+            }
+            plan.passes.push_back(pd);
+            s *= R;
+        }
+        return MI355FFT_OK;
+    }
+    // composite lengths above one workgroup whose factors are 2, 3, 5: two to four general passes (k2g_body)
+    if (n > 4096 && n < ((size_t)1 << 31) && choose_general_radices(plan.prec, n, radices)) {
+        plan.kind = PLAN_MACRO;
+        size_t s = 1;
+        for (size_t p = 0; p < radices.size(); ++p) {
+            const size_t R = radices[p];
+            const KernelEntry* k = find_kernel(p == 0 ? KIND_K2G_FIRST : KIND_K2G_LATER, plan.prec, R);
+            if (k->prepare()) return MI355FFT_ERR_HIP;
+            PassDesc pd{};
+            pd.k = k;
+            pd.m = (long long)(n / R);
+            pd.s = (long long)s;
+            pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(*k), &rc);
+            if (rc) return rc;
+            if (p > 0) {
                 const size_t Q = s * R;
                 int bits = 0;
                 while (((size_t)1 << bits) < Q) ++bits;
@@ -651,14 +728,15 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         p.m = pd.m;
         p.s = pd.s;
         p.batch = (long long)batch;
-        p.tiles_per_fft = pd.m / k.f;
+        const bool general = (k.kind == KIND_K2G_FIRST || k.kind == KIND_K2G_LATER);
+        p.tiles_per_fft = general ? (pd.m + k.f - 1) / k.f : pd.m / k.f;
         p.sgn_in = (inverse && pi == 0) ? (T)-1 : (T)1;
         p.sgn_out = (inverse && pi + 1 == plan.passes.size()) ? (T)-1 : (T)1;
         p.dbg = plan.dbg;
         {
             const long long seg = (long long)k.f * (long long)(2 * sizeof(T));
             long long pair = seg < 128 ? 128 / seg : 1;
-            if ((p.tiles_per_fft * (long long)batch) % (8 * pair) != 0 || (plan.dbg & 2)) pair = 1;
+            if (general || (p.tiles_per_fft * (long long)batch) % (8 * pair) != 0 || (plan.dbg & 2)) pair = 1;
             p.pair = (int)pair;
         }
         grid = (long long)batch * p.tiles_per_fft;

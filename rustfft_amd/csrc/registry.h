@@ -7,7 +7,7 @@
 
 namespace mi355 {
 
-enum KernelKind { KIND_K1 = 1, KIND_K2_FIRST = 2, KIND_K2_LATER = 3, KIND_RADER = 4, KIND_BLUESTEIN = 5, KIND_POINTWISE = 6, KIND_DYN_K1 = 7, KIND_DYN_RADER = 8 };
+enum KernelKind { KIND_K1 = 1, KIND_K2_FIRST = 2, KIND_K2_LATER = 3, KIND_RADER = 4, KIND_BLUESTEIN = 5, KIND_POINTWISE = 6, KIND_DYN_K1 = 7, KIND_DYN_RADER = 8, KIND_K2G_FIRST = 9, KIND_K2G_LATER = 10 };
 
 struct KernelEntry {
     int kind;
@@ -36,6 +36,15 @@ void register_k2_f32(std::vector<KernelEntry>&);
 void register_k2_f64(std::vector<KernelEntry>&);
 void register_np2_f32(std::vector<KernelEntry>&);  // non-power-of-two: mixed radix, Rader, Bluestein
 void register_np2_f64(std::vector<KernelEntry>&);
+// generated: large-N pass kernels for 5-smooth tile heights (tools/gen_k2g_kernels.py)
+void register_k2g_f32_0(std::vector<KernelEntry>&);
+void register_k2g_f32_1(std::vector<KernelEntry>&);
+void register_k2g_f32_2(std::vector<KernelEntry>&);
+void register_k2g_f32_3(std::vector<KernelEntry>&);
+void register_k2g_f64_0(std::vector<KernelEntry>&);
+void register_k2g_f64_1(std::vector<KernelEntry>&);
+void register_k2g_f64_2(std::vector<KernelEntry>&);
+void register_k2g_f64_3(std::vector<KernelEntry>&);
 // generated: compiled schedules for the 7-smooth lengths in (16, 4096] (tools/gen_smooth_kernels.py)
 void register_smooth_f32_0(std::vector<KernelEntry>&);
 void register_smooth_f32_1(std::vector<KernelEntry>&);

@@ -175,15 +175,29 @@ def test_baseline_configs_3_and_4(emu_planner, oracle, dtype):
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_lengths_beyond_one_workgroup(emu_planner, oracle, dtype):
-    """Non-powers of two above 4096 (multi-kernel Bluestein over the large-N passes): a prime the reference plans
-    as Rader (10007), a 'difficult' prime it plans as Bluestein (2879 * 2 + ... -> 5759), a smooth composite (5000 -> RadixN)
-    and a product of two large primes (101 * 103 -> MixedRadix), all four API modes."""
+    """Non-powers of two above 4096: a prime the reference plans as Rader (10007), a 'difficult' prime it plans as
+    Bluestein (5759), a product of two large primes (101 * 103 -> MixedRadix) -- all multi-kernel Bluestein over the
+    large-N passes here -- and a smooth composite (5000 -> RadixN there, two general column-tile passes here)."""
     planner = emu_planner(dtype)
     for n in (4097, 5000, 5759, 10007, 101 * 103):
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
-            assert ("dyn_k1" if n == 5000 else "bluestein_large") in fft.describe()
+            assert ("k2gfirst" if n == 5000 else "bluestein_large") in fft.describe()
             check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=2)
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_general_column_tile_passes(emu_planner, oracle, dtype):
+    """5-smooth lengths above one workgroup (kernels.h k2g_body): 2, 3 and 4 passes, tile heights that do not divide
+    the strides (per-column b mod s), ragged last tiles (M not a multiple of F), pure powers of 3 and 5.  The
+    reference plans these as RadixN / MixedRadix (src/plan.rs:430-560)."""
+    planner = emu_planner(dtype)
+    for n, npass in ((5000, 2), (6000, 2), (10000, 2), (19683, 2), (78125, 2), (98304, 2), (100000, 2), (1000000, 3)):
+        for d in (0, 1):
+            fft = planner.plan_fft(n, d)
+            desc = fft.describe()
+            assert desc.startswith("k2gfirst") and desc.count("->") == npass - 1, desc
+            check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d) if n <= 100000 else None, n=2 if n <= 100000 else 1)
 
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
@@ -192,7 +206,7 @@ def test_runtime_scheduled_kernels(emu_planner, oracle, dtype):
     src/algorithm/radixn.rs:497-541 covers factors 2..7 over small bases; here every compiled radix appears) and
     primes with 13-smooth p - 1 through the run-time scheduled Rader (raders_algorithm.rs:302-309: primes < 100)."""
     planner = emu_planner(dtype)
-    smooth = [3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 22, 26, 33, 39, 55, 65, 77, 91, 121, 143, 169, 1001, 1331, 2310, 4095, 5000]
+    smooth = [3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 22, 26, 33, 39, 55, 65, 77, 91, 121, 143, 169, 1001, 1331, 2310, 4095]
     for n in smooth:
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
