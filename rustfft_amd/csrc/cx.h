@@ -30,6 +30,17 @@ template <class T> struct cx {
 template <class T> MI_HD cx<T> operator+(cx<T> a, cx<T> b) { return {a.re + b.re, a.im + b.im}; }
 template <class T> MI_HD cx<T> operator-(cx<T> a, cx<T> b) { return {a.re - b.re, a.im - b.im}; }
 template <class T> MI_HD cx<T> operator*(cx<T> a, cx<T> b) {
+#if defined(__HIP_DEVICE_COMPILE__) && defined(MI355_PK_CMUL)
+    // f32 on gfx950: two packed instructions, the re/im swap and the sign folded into the op_sel / neg_lo modifiers
+    // (the compiler's own selection materialises swapped copies of loop-invariant factors in extra registers)
+    if constexpr (sizeof(T) == 4) {
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        v2f va = {a.re, a.im}, vb = {b.re, b.im}, t, r;
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(va), "v"(vb));
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(va), "v"(vb), "v"(t));
+        return {r.x, r.y};
+    }
+#endif
     return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
 }
 template <class T> MI_HD cx<T> operator*(cx<T> a, T s) { return {a.re * s, a.im * s}; }

@@ -115,7 +115,16 @@ template <class S, int X> MI_HD int lds_phys(int i) {
 }
 // compile-time part of phys(base + k*step) - phys(base) when it is separable (see above); -1 when it is not
 template <class S> constexpr int lds_step_const(int k, int step, int span /* s_p R_p for scatters, 0 for gathers */) {
-    if (!S::all_pow2() || lds_swizzled<S>()) return -1;
+    if (lds_swizzled<S>()) return -1;
+    if (!S::all_pow2()) {
+        // one padding slot per D = R_0 elements (or none): every stride of the schedule past sub-pass 0 is a multiple
+        // of R_0 and so is every gather step N / R_p, so these layouts are separable as well
+        const int d = S::paddiv();
+        if (d == 0) return k * step;
+        if (step % d == 0) return k * (step + step / d);
+        if (span != 0 && d % step == 0 && span % d == 0) return k * step + (k * step) / d;
+        return -1;
+    }
     if (step % 32 == 0) return k * (step + step / 32);
     if (span != 0 && 32 % step == 0 && span % 32 == 0) return k * step + (k * step) / 32;
     return -1;
@@ -132,13 +141,42 @@ template <Map M, int F, int TPF> MI_HD void map_tid(int tid, int& f, int& u) {
 }
 
 // ---- one sub-pass worth of arithmetic on the registers ------------------------------------------
-template <class T, class S, int P> MI_HD void compute_pass(cx<T>* v, int u, const cx<T>* MI_RESTRICT tw) {
+// Twiddles kept in the thread's register array (kernels that push many sequences through one workgroup load them
+// once): slot TWREG + twreg_offset(P, m) + k - 1 holds the factor of input k of the thread's m-th butterfly in pass P.
+template <class S> constexpr int twreg_offset(int P, int m) {
+    int o = 0;
+    for (int q = 1; q < P; ++q) o += S::bpt(q) * (S::R[q] - 1);
+    return o + (P < S::NP ? m * (S::R[P] - 1) : 0);
+}
+template <class S> constexpr int twreg_count() { return twreg_offset<S>(S::NP, 0); }
+template <class T, class S, int TWREG> MI_HD void preload_twiddles(cx<T>* v, int u, const cx<T>* MI_RESTRICT tw) {
+    static_for<1, S::NP>([&](auto P_) {
+        constexpr int P = P_;
+        constexpr int R = S::R[P], NB = S::nb(P), ST = S::stride(P), BPT = S::bpt(P);
+        static_for<0, BPT>([&](auto M_) {
+            constexpr int m = M_;
+            const int b = u + m * S::TPF;
+            const cx<T>* t = tw + S::tw_offset(P) + (((m + 1) * S::TPF <= NB || b < NB) ? (b % ST) : 0);
+            static_for<1, R>([&](auto K_) {
+                constexpr int k = K_;
+                v[TWREG + twreg_offset<S>(P, m) + k - 1] = t[(k - 1) * ST];
+            });
+        });
+    });
+}
+
+template <class T, class S, int P, int TWREG = -1> MI_HD void compute_pass(cx<T>* v, int u, const cx<T>* MI_RESTRICT tw) {
     constexpr int R = S::R[P], NB = S::nb(P), ST = S::stride(P), BPT = S::bpt(P);
     static_for<0, BPT>([&](auto M_) {
         constexpr int m = M_;
         const int b = u + m * S::TPF;
         if ((m + 1) * S::TPF <= NB || b < NB) {
-            if constexpr (ST > 1) {
+            if constexpr (ST > 1 && TWREG >= 0) {
+                static_for<1, R>([&](auto K_) {
+                    constexpr int k = K_;
+                    v[m * R + k] = v[m * R + k] * v[TWREG + twreg_offset<S>(P, m) + k - 1];
+                });
+            } else if constexpr (ST > 1) {
                 const cx<T>* t = tw + S::tw_offset(P) + (b % ST);
                 static_for<1, R>([&](auto K_) {
                     constexpr int k = K_;
@@ -205,6 +243,15 @@ template <class T, class S, int P, int PART, class E> MI_HD void lds_gather(cx<T
     });
 }
 
+// Destination adaptor: fn(f, i, value, integral_constant<slot>, v) also sees the compile-time register slot of the
+// value and the thread's register array (for tables a kernel keeps next to the data registers).
+template <class L> struct SlotDst {
+    L fn;
+};
+template <class L> MI_HD SlotDst<L> slot_dst(L l) { return SlotDst<L>{l}; }
+template <class D> struct is_slot_dst : std::false_type {};
+template <class L> struct is_slot_dst<SlotDst<L>> : std::true_type {};
+
 template <class S, int P, Map MIN, Map MOUT> constexpr Map pass_map() {
     return P == 0 ? MIN : (P == S::NP - 1 ? MOUT : MAP_EF);
 }
@@ -215,7 +262,7 @@ template <class S, int P, Map MIN, Map MOUT> constexpr Map pass_map() {
 // src(f, i) -> cx<T>: input element i of sequence f;   dst(f, i, value): output element i.
 // ABL (compile-time, tuning builds only): bit 2 skips the arithmetic, bit 3 skips the LDS exchange — ablation probes
 // that keep the HBM access pattern; production instantiations use ABL = 0.
-template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, int PM, int ABL, int P, class X, class SRC, class DST>
+template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, int PM, int ABL, int P, int TWREG = -1, class X, class SRC, class DST>
 MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& src, DST& dst) {
     constexpr int R = S::R[P], NB = S::nb(P), ST = S::stride(P), BPT = S::bpt(P);
     constexpr Map MP = pass_map<S, P, MIN, MOUT>();
@@ -224,7 +271,7 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
     ex.for_threads([&](int tid, cx<T>* v) {
         int f, u;
         map_tid<MP, F, S::TPF>(tid, f, u);
-        if constexpr (!(ABL & 4)) compute_pass<T, S, P>(v, u, tw);
+        if constexpr (!(ABL & 4)) compute_pass<T, S, P, TWREG>(v, u, tw);
         if constexpr (LAST) {
             static_for<0, BPT>([&](auto M_) {
                 constexpr int m = M_;
@@ -233,7 +280,12 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
                     const int base = (b / ST) * (ST * R) + (b % ST);
                     static_for<0, R>([&](auto K_) {
                         constexpr int k = K_;
-                        dst(f, base + k * ST, v[m * R + k]);
+                        // destinations that keep per-output tables in the register array also get the
+                        // compile-time slot of the value and the array itself
+                        if constexpr (is_slot_dst<DST>::value)
+                            dst.fn(f, base + k * ST, v[m * R + k], std::integral_constant<int, m * R + k>{}, v);
+                        else
+                            dst(f, base + k * ST, v[m * R + k]);
                     });
                 }
             });
@@ -245,7 +297,7 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
         }
     });
     if constexpr (!LAST && (ABL & 8) != 0) {
-        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, P + 1>(ex, lds_raw, tw, src, dst);
+        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, P + 1, TWREG>(ex, lds_raw, tw, src, dst);
     } else if constexpr (!LAST) {
         constexpr Map MQ = pass_map<S, P + 1, MIN, MOUT>();
         ex.barrier();
@@ -279,7 +331,7 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
             });
             ex.barrier();
         }
-        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, P + 1>(ex, lds_raw, tw, src, dst);
+        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, P + 1, TWREG>(ex, lds_raw, tw, src, dst);
     }
 }
 
@@ -306,7 +358,7 @@ template <class T, class S, int F, bool SPLIT, int PM = 1> constexpr size_t lds_
 
 // SRC_IN_LDS: `src` reads the same LDS buffer the exchanges use (Rader/Bluestein second transform), so a
 // barrier separates the loads from the first scatter.
-template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, bool SRC_IN_LDS = false, int PM = 1, int ABL = 0, class X, class SRC, class DST>
+template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, bool SRC_IN_LDS = false, int PM = 1, int ABL = 0, int TWREG = -1, class X, class SRC, class DST>
 MI_HD void wg_fft(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC src, DST dst) {
     static_assert(S::valid(), "radices must multiply to N");
     constexpr int R0 = S::R[0], NB0 = S::nb(0), BPT0 = S::bpt(0);
@@ -324,7 +376,7 @@ MI_HD void wg_fft(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC src, DS
         });
     });
     if constexpr (SRC_IN_LDS) ex.barrier();
-    wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, 0>(ex, lds_raw, tw, src, dst);
+    wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, 0, TWREG>(ex, lds_raw, tw, src, dst);
 }
 
 }  // namespace mi355

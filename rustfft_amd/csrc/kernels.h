@@ -357,9 +357,12 @@ template <class T> MI_HD void pointwise_elem(const PointwiseParams<T>& p, long l
 }
 
 // ---- Rader: prime length p = S::N + 1 ---------------------------------------------------------------------
-// LDS: [F][PITCH] exchange/work buffer followed by [F][p] staging of the rows (the g^j permutations are
-// random within a row, so they are applied against LDS, never against HBM).
-template <class T, class S, int F, class X>
+// MODE 0 -- LDS: [F][PITCH] exchange/work buffer followed by [F][p] staging of the rows (the g^j permutations are
+//   random within a row, so they are applied against LDS, never against HBM).
+// MODE 1 -- one [F][PITCH] buffer: the coalesced load scatters x[t] straight to its convolution slot (perm_in holds the
+//   INVERSE map t -> j with g^(j+1) = t), both transforms read their inputs linearly from LDS, and the second transform
+//   scatters its outputs to their final positions in the same buffer.  Half the LDS, one LDS round trip fewer.
+template <class T, class S, int F, int MODE, class X>
 MI_HD void rader_body(X& ex, const RaderParams<T>& p, long long block, void* lds) {
     constexpr int M = S::N, P = S::N + 1, PITCH = S::pitch(), NT = F * S::TPF;
     const long long fft0 = block * F;
@@ -371,48 +374,205 @@ MI_HD void rader_body(X& ex, const RaderParams<T>& p, long long block, void* lds
     const long long batch = p.batch;
     const T sgn = p.sgn;
     cx<T>* work = (cx<T>*)lds;
-    cx<T>* rows = work + F * PITCH;
     const long long rows_here = (batch - fft0) < F ? (batch - fft0) : F;
     const int valid = (int)(rows_here * P);
-    // coalesced flat copy of this workgroup's rows into LDS
-    ex.for_threads([&](int tid, cx<T>*) {
-        for (int t = tid; t < F * P; t += NT) {
-            cx<T> x = cx<T>{0, 0};
-            if (t < valid) {
-                x = in[fft0 * P + t];
-                x.im *= sgn;
+    if constexpr (MODE == 1) {
+        constexpr int XS = S::phys(M - 1) + 1;  // first slot past the exchange span: x[0], then X[0]
+        static_assert(XS < PITCH && P <= PITCH, "row pitch must leave a spare slot");
+        ex.for_threads([&](int tid, cx<T>*) {
+            for (int t = tid; t < F * P; t += NT) {
+                const int f = t / P, i = t - f * P;
+                cx<T> x = cx<T>{0, 0};
+                if (t < valid) {
+                    x = in[fft0 * P + t];
+                    x.im *= sgn;
+                }
+                work[f * PITCH + (i == 0 ? XS : perm_in[i])] = x;
             }
-            rows[t] = x;
-        }
+        });
+        ex.barrier();
+        auto src1 = [=](int f, int j) -> cx<T> { return work[f * PITCH + j]; };
+        auto dst1 = [=](int f, int j, cx<T> v) {
+            cx<T> t = cconj(v * dtab[j]);
+            if (j == 0) {
+                const cx<T> x0 = work[f * PITCH + XS];
+                t = t + cconj(x0);
+                work[f * PITCH + XS] = x0 + v;  // X[0]
+            }
+            work[f * PITCH + j] = t;
+        };
+        wg_fft<T, S, F, MAP_EF, MAP_EF, false, true>(ex, lds, p.tw, elem_src(src1), dst1);
+        ex.barrier();
+        auto dst2 = [=](int f, int j, cx<T> v) {
+            if (j == 0) work[f * PITCH] = work[f * PITCH + XS];  // slot 0 is no target of the g^-j scatter
+            work[f * PITCH + perm_out[j]] = cconj(v);
+        };
+        wg_fft<T, S, F, MAP_EF, MAP_EF, false, true>(ex, lds, p.tw, elem_src(src1), dst2);
+        ex.barrier();
+        ex.for_threads([&](int tid, cx<T>*) {
+            for (int t = tid; t < valid; t += NT) {
+                const int f = t / P, i = t - f * P;
+                cx<T> y = work[f * PITCH + i];
+                y.im *= sgn;
+                out[fft0 * P + t] = y;
+            }
+        });
+    } else {
+        cx<T>* rows = work + F * PITCH;
+        // coalesced flat copy of this workgroup's rows into LDS
+        ex.for_threads([&](int tid, cx<T>*) {
+            for (int t = tid; t < F * P; t += NT) {
+                cx<T> x = cx<T>{0, 0};
+                if (t < valid) {
+                    x = in[fft0 * P + t];
+                    x.im *= sgn;
+                }
+                rows[t] = x;
+            }
+        });
+        ex.barrier();
+        auto src1 = [=](int f, int j) -> cx<T> { return rows[f * P + perm_in[j]]; };
+        auto dst1 = [=](int f, int j, cx<T> v) {
+            cx<T> t = cconj(v * dtab[j]);
+            if (j == 0) {
+                const cx<T> x0 = rows[f * P];
+                t = t + cconj(x0);
+                work[f * PITCH + M] = x0 + v;  // X[0]; slot M of the row is outside the transform's span (PITCH > M)
+            }
+            work[f * PITCH + j] = t;
+        };
+        wg_fft<T, S, F, MAP_EF, MAP_EF, false>(ex, lds, p.tw, elem_src(src1), dst1);
+        ex.barrier();
+        // X[0] must leave `work` before the second transform's exchanges reuse the buffer
+        ex.for_threads([&](int tid, cx<T>*) {
+            if (tid < F) rows[tid * P] = work[tid * PITCH + M];
+        });
+        auto src2 = [=](int f, int i) -> cx<T> { return work[f * PITCH + i]; };
+        auto dst2 = [=](int f, int j, cx<T> v) { rows[f * P + perm_out[j]] = cconj(v); };
+        wg_fft<T, S, F, MAP_EF, MAP_EF, false, true>(ex, lds, p.tw, elem_src(src2), dst2);
+        ex.barrier();
+        ex.for_threads([&](int tid, cx<T>*) {
+            for (int t = tid; t < valid; t += NT) {
+                cx<T> y = rows[t];
+                y.im *= sgn;
+                out[fft0 * P + t] = y;
+            }
+        });
+    }
+}
+
+// ---- Rader, many rows per workgroup (MODE 2) ---------------------------------------------------------------
+// The MODE 1 flow, but one workgroup pushes ROWS rows through the same LDS buffer one after another and keeps every
+// per-thread table in registers across rows: the sub-pass twiddles, the d[] factors and g^-j targets of the thread's
+// last-pass outputs, the scatter slots of the elements it loads, and the NEXT row's elements (prefetched while the
+// current row is transformed).  Per row only x is read and X written; all index arithmetic is loop-invariant.
+template <class T> MI_HD cx<T> idx_to_reg(int i) {
+    cx<T> r{0, 0};
+    if constexpr (sizeof(T) == 4)
+        r.re = __builtin_bit_cast(T, i);
+    else
+        r.re = __builtin_bit_cast(T, (long long)i);
+    return r;
+}
+template <class T> MI_HD int reg_to_idx(const cx<T>& r) {
+    if constexpr (sizeof(T) == 4)
+        return __builtin_bit_cast(int, r.re);
+    else
+        return (int)__builtin_bit_cast(long long, r.re);
+}
+template <class S> struct RaderRows {
+    static constexpr int M = S::N, P = S::N + 1, NT = S::TPF, EM = S::emax();
+    static constexpr int NL = (P + NT - 1) / NT;  // elements of a row each thread loads / stores
+    static constexpr int TW0 = EM, D0 = TW0 + twreg_count<S>(), PO0 = D0 + EM, PI0 = PO0 + EM, XN0 = PI0 + NL, NREG = XN0 + NL;
+    static constexpr int XS = S::phys(M - 1) + 1;  // first slot past the exchange span: x[0], then X[0]; XS + 1: dump slot
+};
+template <class T, class S, int ROWS, bool PREFETCH, class X>
+MI_HD void rader_rows_body(X& ex, const RaderParams<T>& p, long long block, void* lds) {
+    using L = RaderRows<S>;
+    constexpr int P = L::P, PITCH = S::pitch(), NT = L::NT, NL = L::NL, XS = L::XS;
+    static_assert(XS + 1 < PITCH && P <= PITCH, "row pitch must leave two spare slots");
+    const cx<T>* MI_RESTRICT in = p.in;
+    cx<T>* MI_RESTRICT out = p.out;
+    const T sgn = p.sgn;
+    cx<T>* work = (cx<T>*)lds;
+    const long long row0 = block * ROWS;
+    const long long row_end = (row0 + ROWS < p.batch) ? row0 + ROWS : p.batch;
+    ex.for_threads([&](int tid, cx<T>* v) {
+        preload_twiddles<T, S, L::TW0>(v, tid, p.tw);
+        constexpr int LP = S::NP - 1, R = S::R[LP], NB = S::nb(LP), ST = S::stride(LP), BPT = S::bpt(LP);
+        static_for<0, BPT>([&](auto M_) {
+            constexpr int m = M_;
+            const int b = tid + m * S::TPF;
+            const int bb = ((m + 1) * S::TPF <= NB || b < NB) ? b : 0;
+            const int base = (bb / ST) * (ST * R) + (bb % ST);
+            static_for<0, R>([&](auto K_) {
+                constexpr int k = K_;
+                v[L::D0 + m * R + k] = p.d[base + k * ST];
+                v[L::PO0 + m * R + k] = idx_to_reg<T>(p.perm_out[base + k * ST]);
+            });
+        });
+        static_for<0, NL>([&](auto I_) {
+            constexpr int i = I_;
+            const int t = tid + i * NT;
+            v[L::PI0 + i] = idx_to_reg<T>(t == 0 ? XS : (t < P ? p.perm_in[t] : XS + 1));
+            if constexpr (PREFETCH) v[L::XN0 + i] = (t < P && row0 < row_end) ? in[row0 * P + t] : cx<T>{0, 0};
+        });
     });
-    ex.barrier();
-    auto src1 = [=](int f, int j) -> cx<T> { return rows[f * P + perm_in[j]]; };
-    auto dst1 = [=](int f, int j, cx<T> v) {
-        cx<T> t = cconj(v * dtab[j]);
+    auto src = [=](int, int j) -> cx<T> { return work[j]; };
+    auto dst1 = [=](int, int j, cx<T> val, auto I_, cx<T>* v) {
+        cx<T> t = cconj(val * v[L::D0 + decltype(I_)::value]);
         if (j == 0) {
-            const cx<T> x0 = rows[f * P];
+            const cx<T> x0 = work[XS];
             t = t + cconj(x0);
-            work[f * PITCH + M] = x0 + v;  // X[0]; slot M of the row is outside the transform's span (PITCH > M)
+            work[XS] = x0 + val;  // X[0]
         }
-        work[f * PITCH + j] = t;
+        work[j] = t;
     };
-    wg_fft<T, S, F, MAP_EF, MAP_EF, false>(ex, lds, p.tw, elem_src(src1), dst1);
-    ex.barrier();
-    // X[0] must leave `work` before the second transform's exchanges reuse the buffer
-    ex.for_threads([&](int tid, cx<T>*) {
-        if (tid < F) rows[tid * P] = work[tid * PITCH + M];
-    });
-    auto src2 = [=](int f, int i) -> cx<T> { return work[f * PITCH + i]; };
-    auto dst2 = [=](int f, int j, cx<T> v) { rows[f * P + perm_out[j]] = cconj(v); };
-    wg_fft<T, S, F, MAP_EF, MAP_EF, false, true>(ex, lds, p.tw, elem_src(src2), dst2);
-    ex.barrier();
-    ex.for_threads([&](int tid, cx<T>*) {
-        for (int t = tid; t < valid; t += NT) {
-            cx<T> y = rows[t];
-            y.im *= sgn;
-            out[fft0 * P + t] = y;
-        }
-    });
+    auto dst2 = [=](int, int j, cx<T> val, auto I_, cx<T>* v) {
+        if (j == 0) work[0] = work[XS];  // slot 0 is no target of the g^-j scatter
+        work[reg_to_idx<T>(v[L::PO0 + decltype(I_)::value])] = cconj(val);
+    };
+    for (long long row = row0; row < row_end; ++row) {
+        ex.relaunder();
+        ex.for_threads([&](int tid, cx<T>* v) {
+            static_for<0, NL>([&](auto I_) {
+                constexpr int i = I_;
+                cx<T> x;
+                if constexpr (PREFETCH) {
+                    x = v[L::XN0 + i];
+                } else {
+                    const int t = tid + i * NT;
+                    x = ((i + 1) * NT <= P || t < P) ? in[row * P + t] : cx<T>{0, 0};
+                }
+                x.im *= sgn;
+                work[reg_to_idx<T>(v[L::PI0 + i])] = x;
+            });
+            if (PREFETCH && row + 1 < row_end) {
+                static_for<0, NL>([&](auto I_) {
+                    constexpr int i = I_;
+                    const int t = tid + i * NT;
+                    if ((i + 1) * NT <= P || t < P) v[L::XN0 + i] = in[(row + 1) * P + t];
+                });
+            }
+        });
+        ex.barrier();
+        wg_fft<T, S, 1, MAP_EF, MAP_EF, false, true, 1, 0, L::TW0>(ex, lds, p.tw, elem_src(src), slot_dst(dst1));
+        ex.barrier();
+        wg_fft<T, S, 1, MAP_EF, MAP_EF, false, true, 1, 0, L::TW0>(ex, lds, p.tw, elem_src(src), slot_dst(dst2));
+        ex.barrier();
+        ex.for_threads([&](int tid, cx<T>*) {
+            static_for<0, NL>([&](auto I_) {
+                constexpr int i = I_;
+                const int t = tid + i * NT;
+                if ((i + 1) * NT <= P || t < P) {
+                    cx<T> y = work[t];
+                    y.im *= sgn;
+                    out[row * P + t] = y;
+                }
+            });
+        });
+        ex.barrier();
+    }
 }
 
 }  // namespace mi355

@@ -1,13 +1,22 @@
 // Non-power-of-two instantiations, Complex<float>: native mixed radix for BASELINE config 3 (N = 1200),
 // Rader for config 4 (N = 1009, inner 1008 = 16 x 9 x 7) and the Bluestein bodies that cover every other length.
+// The Rader / Bluestein bodies are VALU-issue bound, not HBM bound: this unit opts into cx.h's two-instruction packed
+// complex multiply (measured on MI355X: Rader 1009 +16 %; the HBM-bound pow2 tiles lose 3-6 % with it and keep the
+// compiler's own selection).
+#define MI355_PK_CMUL 1
 #include "launch.h"
 #include "kernel_lists.h"
 namespace mi355 {
 void register_np2_f32(std::vector<KernelEntry>& reg) {
     MI_K1(float, 32, 2, false, 1200, 120, 10, 10, 12);
-    MI_RADER(float, 32, 1, 1008, 144, 16, 9, 7);  // one row per workgroup: more independent workgroups per CU (+11 % over two rows)
-    MI_RADERV(1, float, 32, 2, 1008, 144, 16, 9, 7);
-    MI_RADERV(2, float, 32, 2, 1008, 63, 16, 9, 7);  // tuning: one wave per row, up to 21 values per thread (slower)
+    // Rader 1009: eight rows per workgroup, one after another, every per-thread table in registers (kernels.h
+    // rader_rows_body).  Measured on MI355X (2 GiB of rows): 3.0 TB/s, against 2.3 (one row per workgroup, staged rows,
+    // variant 1), 2.1 (variant 2: scatter on load, 128 threads) and 2.4 (variant 4: no prefetch of the next row).
+    MI_RADER(float, 32, 8, 2, 1008, 144, 16, 9, 7);
+    MI_RADERV(1, float, 32, 1, 0, 1008, 144, 16, 9, 7);
+    MI_RADERV(2, float, 32, 1, 1, 1008, 128, 16, 9, 7);
+    MI_RADERV(3, float, 32, 32, 2, 1008, 144, 16, 9, 7);
+    MI_RADERV(4, float, 32, 8, 3, 1008, 144, 16, 9, 7);
     MI_BS_LIST(float, 32);
     MI_BS_LIST3_F32(float, 32);
     reg.push_back(make_pointwise<float>(32));

@@ -15,6 +15,17 @@ template <class T, int NREG> struct DevExec {
     cx<T> v[NREG];
     template <class Fn> __device__ __forceinline__ void for_threads(Fn&& fn) { fn((int)threadIdx.x, v); }
     __device__ __forceinline__ void barrier() { __syncthreads(); }
+    __device__ __forceinline__ void relaunder() {}
+};
+// Executor for bodies that loop over many sequences: relaunder() makes the thread index opaque to the optimiser from
+// there on, so the (cheap) index arithmetic is redone per sequence instead of being hoisted out of the loop into
+// hundreds of live registers.
+template <class T, int NREG> struct DevExecLoop {
+    cx<T> v[NREG];
+    int tid = (int)threadIdx.x;
+    template <class Fn> __device__ __forceinline__ void for_threads(Fn&& fn) { fn(tid, v); }
+    __device__ __forceinline__ void barrier() { __syncthreads(); }
+    __device__ __forceinline__ void relaunder() { asm volatile("" : "+v"(tid)); }
 };
 
 template <class T, class S, int F, bool SPLIT, int ABL = 0>
@@ -82,11 +93,16 @@ __global__ __launch_bounds__(F* S::TPF) void bluestein_kernel(BluesteinParams<T>
     DevExec<T, regs_needed<S, false>()> ex;
     bluestein_body<T, S, F>(ex, p, (long long)blockIdx.x, smem);
 }
-template <class T, class S, int F>
-__global__ __launch_bounds__(F* S::TPF) void rader_kernel(RaderParams<T> p) {
+template <class T, class S, int F, int MODE>
+__global__ __launch_bounds__((MODE >= 2 ? 1 : F) * S::TPF, (MODE == 2 ? (sizeof(T) == 4 ? 3 : 2) : MODE == 3 ? (sizeof(T) == 4 ? 4 : 2) : 1)) void rader_kernel(RaderParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    DevExec<T, regs_needed<S, false>()> ex;
-    rader_body<T, S, F>(ex, p, (long long)blockIdx.x, smem);
+    if constexpr (MODE >= 2) {  // F = rows pushed through one workgroup one after another
+        DevExecLoop<T, RaderRows<S>::NREG> ex;
+        rader_rows_body<T, S, F, MODE == 2>(ex, p, (long long)blockIdx.x, smem);
+    } else {
+        DevExec<T, regs_needed<S, false>()> ex;
+        rader_body<T, S, F, MODE>(ex, p, (long long)blockIdx.x, smem);
+    }
 }
 template <class T> __global__ __launch_bounds__(256) void pointwise_kernel(PointwiseParams<T> p, long long total) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) pointwise_elem<T>(p, i);
@@ -107,7 +123,9 @@ template <class T> KernelEntry make_pointwise(int prec) {
     return e;
 }
 template <class T, class S, int F> constexpr size_t bluestein_lds() { return (size_t)F * S::pitch() * sizeof(cx<T>); }
-template <class T, class S, int F> constexpr size_t rader_lds() { return (size_t)F * (S::pitch() + S::N + 1) * sizeof(cx<T>); }
+template <class T, class S, int F, int MODE> constexpr size_t rader_lds() {
+    return (size_t)(MODE >= 2 ? 1 : F) * (S::pitch() + (MODE >= 1 ? 0 : S::N + 1)) * sizeof(cx<T>);
+}
 
 template <class T, class S, int F> KernelEntry make_bluestein(int prec, const char* name) {
     KernelEntry e{};
@@ -130,25 +148,26 @@ template <class T, class S, int F> KernelEntry make_bluestein(int prec, const ch
     };
     return e;
 }
-template <class T, class S, int F> KernelEntry make_rader(int prec, const char* name) {
+template <class T, class S, int F, int MODE> KernelEntry make_rader(int prec, const char* name) {
     KernelEntry e{};
+    e.split = (MODE >= 1);  // Rader: perm_in is the inverse map (kernels.h rader_body MODE 1, rader_rows_body)
     e.kind = KIND_RADER;
     e.prec = prec;
     e.n = S::N;
     e.aux = S::N + 1;
     e.f = F;
     fill_sched<S>(e);
-    e.threads = F * S::TPF;
-    e.lds_bytes = rader_lds<T, S, F>();
+    e.threads = (MODE >= 2 ? 1 : F) * S::TPF;
+    e.lds_bytes = rader_lds<T, S, F, MODE>();
     e.name = name;
     e.launch = [](const void* params, long long grid, void* stream) {
         void* args[] = {const_cast<void*>(params)};
-        (void)hipLaunchKernel((const void*)rader_kernel<T, S, F>, dim3((unsigned)grid), dim3(F * S::TPF), args,
-                              rader_lds<T, S, F>(), (hipStream_t)stream);
+        (void)hipLaunchKernel((const void*)rader_kernel<T, S, F, MODE>, dim3((unsigned)grid), dim3((MODE >= 2 ? 1 : F) * S::TPF), args,
+                              rader_lds<T, S, F, MODE>(), (hipStream_t)stream);
     };
     e.prepare = []() -> int {
-        return (int)hipFuncSetAttribute((const void*)rader_kernel<T, S, F>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)rader_lds<T, S, F>());
+        return (int)hipFuncSetAttribute((const void*)rader_kernel<T, S, F, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)rader_lds<T, S, F, MODE>());
     };
     return e;
 }
@@ -239,6 +258,7 @@ template <class T, int NREG> struct HostExec {
         for (int t = 0; t < nt; ++t) fn(t, regs.data() + (size_t)t * NREG);
     }
     void barrier() {}
+    void relaunder() {}
 };
 template <class T, class S, int F, bool SPLIT, int ABL = 0> KernelEntry make_k1(int prec, const char* name) {
     KernelEntry e{};
@@ -295,7 +315,9 @@ template <class T> KernelEntry make_pointwise(int prec) {
     return e;
 }
 template <class T, class S, int F> constexpr size_t bluestein_lds() { return (size_t)F * S::pitch() * sizeof(cx<T>); }
-template <class T, class S, int F> constexpr size_t rader_lds() { return (size_t)F * (S::pitch() + S::N + 1) * sizeof(cx<T>); }
+template <class T, class S, int F, int MODE> constexpr size_t rader_lds() {
+    return (size_t)(MODE >= 2 ? 1 : F) * (S::pitch() + (MODE >= 1 ? 0 : S::N + 1)) * sizeof(cx<T>);
+}
 template <class T, class S, int F> KernelEntry make_bluestein(int prec, const char* name) {
     KernelEntry e{};
     e.kind = KIND_BLUESTEIN;
@@ -316,22 +338,28 @@ template <class T, class S, int F> KernelEntry make_bluestein(int prec, const ch
     e.prepare = []() -> int { return 0; };
     return e;
 }
-template <class T, class S, int F> KernelEntry make_rader(int prec, const char* name) {
+template <class T, class S, int F, int MODE> KernelEntry make_rader(int prec, const char* name) {
     KernelEntry e{};
+    e.split = (MODE >= 1);  // Rader: perm_in is the inverse map (kernels.h rader_body MODE 1, rader_rows_body)
     e.kind = KIND_RADER;
     e.prec = prec;
     e.n = S::N;
     e.aux = S::N + 1;
     e.f = F;
     fill_sched<S>(e);
-    e.threads = F * S::TPF;
-    e.lds_bytes = rader_lds<T, S, F>();
+    e.threads = (MODE >= 2 ? 1 : F) * S::TPF;
+    e.lds_bytes = rader_lds<T, S, F, MODE>();
     e.name = name;
     e.launch = [](const void* params, long long grid, void*) {
-        std::vector<char> lds(rader_lds<T, S, F>() + 64, (char)0x5a);
+        std::vector<char> lds(rader_lds<T, S, F, MODE>() + 64, (char)0x5a);
         for (long long b = 0; b < grid; ++b) {
-            HostExec<T, regs_needed<S, false>()> ex(F * S::TPF);
-            rader_body<T, S, F>(ex, *(const RaderParams<T>*)params, b, lds.data());
+            if constexpr (MODE >= 2) {
+                HostExec<T, RaderRows<S>::NREG> ex(S::TPF);
+                rader_rows_body<T, S, F, MODE == 2>(ex, *(const RaderParams<T>*)params, b, lds.data());
+            } else {
+                HostExec<T, regs_needed<S, false>()> ex(F * S::TPF);
+                rader_body<T, S, F, MODE>(ex, *(const RaderParams<T>*)params, b, lds.data());
+            }
         }
     };
     e.prepare = []() -> int { return 0; };
@@ -423,9 +451,9 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
     reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, true>(PREC, "k2gfirst<" #__VA_ARGS__ ">xF" #F));  \
     reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, false>(PREC, "k2glater<" #__VA_ARGS__ ">xF" #F))
 #define MI_BS(T, PREC, F, ...) reg.push_back(make_bluestein<T, Sched<__VA_ARGS__>, F>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F))
-#define MI_RADER(T, PREC, F, ...) reg.push_back(make_rader<T, Sched<__VA_ARGS__>, F>(PREC, "rader<" #__VA_ARGS__ ">xF" #F))
-#define MI_RADERV(V, T, PREC, F, ...)                                                                   \
-    reg.push_back(make_rader<T, Sched<__VA_ARGS__>, F>(PREC, "rader<" #__VA_ARGS__ ">xF" #F "v" #V)); \
+#define MI_RADER(T, PREC, F, MODE, ...) reg.push_back(make_rader<T, Sched<__VA_ARGS__>, F, MODE>(PREC, "rader<" #__VA_ARGS__ ">xF" #F "m" #MODE))
+#define MI_RADERV(V, T, PREC, F, MODE, ...)                                                                   \
+    reg.push_back(make_rader<T, Sched<__VA_ARGS__>, F, MODE>(PREC, "rader<" #__VA_ARGS__ ">xF" #F "m" #MODE "v" #V)); \
     reg.back().variant = V
 
 }  // namespace mi355

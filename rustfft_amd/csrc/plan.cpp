@@ -480,6 +480,11 @@ template <class T> static int build_plan_t(Plan& plan) {
             pout[j] = (int)b;
         }
         host_dft(d);
+        if (e.split) {  // MODE 1 bodies scatter on load: they want the inverse map t -> j with g^(j+1) = t
+            std::vector<int> inv(pp, 0);
+            for (size_t j = 0; j + 1 < pp; ++j) inv[(size_t)pin[j]] = (int)j;
+            pin.swap(inv);
+        }
         plan.kind = PLAN_RADER;
         PassDesc pd{};
         pd.k = &e;

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--sizes", default="", help="comma-separated explicit lengths (overrides --min/--max)")
+    ap.add_argument("--lib", default="", help="A/B runs: load this build of libmi355fft.so instead of rustfft_amd/lib's")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -26,7 +27,12 @@ def main():
     import rustfft_amd
 
     dt, tdt, esz = (np.complex64, torch.complex64, 8) if args.dtype == "f32" else (np.complex128, torch.complex128, 16)
-    planner = rustfft_amd.FftPlanner(dt)
+    if args.lib:
+        from rustfft_amd import _native
+
+        planner = rustfft_amd.FftPlannerHip(dt, lib=_native.load(args.lib))
+    else:
+        planner = rustfft_amd.FftPlanner(dt)
     sizes = [int(v) for v in args.sizes.split(",")] if args.sizes else [1 << q for q in range(args.min, args.max + 1)]
     for n in sizes:
         p = math.log2(n)
