@@ -25,7 +25,13 @@ namespace mi355 {
 
 enum Map { MAP_EF = 0, MAP_FF = 1 };
 
-template <int N_, int TPF_, int... Rs> struct Sched {
+
+
+// LIN: power-of-two schedules normally exchange through the XOR-swizzled layout; LIN = true selects the linear (padded)
+// layout instead (SchedL below) -- the swizzle needs one live address register per element, which the two-transform
+// bodies (Bluestein) cannot afford.  The choice is part of the type, so both can coexist in one library.
+template <bool LIN, int N_, int TPF_, int... Rs> struct SchedImpl {
+    static constexpr bool kLinearLds = LIN;
     static constexpr int N = N_, TPF = TPF_, NP = (int)sizeof...(Rs);
     static constexpr int R[sizeof...(Rs)] = {Rs...};
     static constexpr int radix(int p) { return R[p]; }
@@ -68,7 +74,7 @@ template <int N_, int TPF_, int... Rs> struct Sched {
     static constexpr int paddiv() { return (!all_pow2() && NP > 1 && R[0] % 2 == 0) ? R[0] : 0; }
     static constexpr int phys(int i) {
         constexpr int d = paddiv();
-        if constexpr (all_pow2() && emax() > 16)
+        if constexpr (all_pow2() && (emax() > 16 || kLinearLds))
             return i + i / 32;
         else if constexpr (d != 0)
             return i + i / d;
@@ -89,6 +95,8 @@ template <int N_, int TPF_, int... Rs> struct Sched {
         return prod == N;
     }
 };
+template <int N_, int TPF_, int... Rs> struct Sched : SchedImpl<false, N_, TPF_, Rs...> {};
+template <int N_, int TPF_, int... Rs> struct SchedL : SchedImpl<true, N_, TPF_, Rs...> {};
 
 // Two layouts for power-of-two schedules:
 //  * swizzle (threads holding <= 16 values): XOR the run index of the scatter into the bank bits.  Sub-pass x scatters
@@ -97,7 +105,7 @@ template <int N_, int TPF_, int... Rs> struct Sched {
 //    (measured: SQ_LDS_BANK_CONFLICT 43 % -> 0 of the LDS cycles).
 //  * linear (the 32-values-per-thread tiles): one padding slot per 32 elements; 2-4-way conflicts remain on some
 //    patterns, but every address is base + constant, which is what keeps those kernels from spilling.
-template <class S> constexpr bool lds_swizzled() { return S::all_pow2() && S::emax() <= 16; }
+template <class S> constexpr bool lds_swizzled() { return S::all_pow2() && S::emax() <= 16 && !S::kLinearLds; }
 template <class S, int X> MI_HD int lds_phys(int i) {
     if constexpr (lds_swizzled<S>()) {
         constexpr int ST = S::stride(X), SR = S::stride(X) * S::R[X];
@@ -161,6 +169,21 @@ template <class T, class S, int TWREG> MI_HD void preload_twiddles(cx<T>* v, int
                 constexpr int k = K_;
                 v[TWREG + twreg_offset<S>(P, m) + k - 1] = t[(k - 1) * ST];
             });
+        });
+    });
+}
+
+// the same for one sub-pass: issued next to the gather that precedes the pass, i.e. BEFORE the barrier, so the table
+// look-up's latency overlaps the barrier instead of following it (TWSTAGE kernels)
+template <class T, class S, int P, int TWREG> MI_HD void preload_twiddles_pass(cx<T>* v, int u, const cx<T>* MI_RESTRICT tw) {
+    constexpr int R = S::R[P], NB = S::nb(P), ST = S::stride(P), BPT = S::bpt(P);
+    static_for<0, BPT>([&](auto M_) {
+        constexpr int m = M_;
+        const int b = u + m * S::TPF;
+        const cx<T>* t = tw + S::tw_offset(P) + (((m + 1) * S::TPF <= NB || b < NB) ? (b % ST) : 0);
+        static_for<1, R>([&](auto K_) {
+            constexpr int k = K_;
+            v[TWREG + twreg_offset<S>(P, m) + k - 1] = t[(k - 1) * ST];
         });
     });
 }
@@ -262,7 +285,7 @@ template <class S, int P, Map MIN, Map MOUT> constexpr Map pass_map() {
 // src(f, i) -> cx<T>: input element i of sequence f;   dst(f, i, value): output element i.
 // ABL (compile-time, tuning builds only): bit 2 skips the arithmetic, bit 3 skips the LDS exchange — ablation probes
 // that keep the HBM access pattern; production instantiations use ABL = 0.
-template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, int PM, int ABL, int P, int TWREG = -1, class X, class SRC, class DST>
+template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, int PM, int ABL, int P, int TWREG = -1, bool TWSTAGE = false, class X, class SRC, class DST>
 MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& src, DST& dst) {
     constexpr int R = S::R[P], NB = S::nb(P), ST = S::stride(P), BPT = S::bpt(P);
     constexpr Map MP = pass_map<S, P, MIN, MOUT>();
@@ -297,7 +320,7 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
         }
     });
     if constexpr (!LAST && (ABL & 8) != 0) {
-        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, P + 1, TWREG>(ex, lds_raw, tw, src, dst);
+        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, P + 1, TWREG, TWSTAGE>(ex, lds_raw, tw, src, dst);
     } else if constexpr (!LAST) {
         constexpr Map MQ = pass_map<S, P + 1, MIN, MOUT>();
         ex.barrier();
@@ -306,6 +329,7 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
                 int f, u;
                 map_tid<MQ, F, S::TPF>(tid, f, u);
                 lds_gather<T, S, P + 1, 0>(v, u, (const cx<T>*)lds_raw + f * S::template pitch_for<PM>());
+                if constexpr (TWSTAGE && TWREG >= 0) preload_twiddles_pass<T, S, P + 1, TWREG>(v, u, tw);
             });
             ex.barrier();
         } else {
@@ -331,7 +355,7 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
             });
             ex.barrier();
         }
-        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, P + 1, TWREG>(ex, lds_raw, tw, src, dst);
+        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, P + 1, TWREG, TWSTAGE>(ex, lds_raw, tw, src, dst);
     }
 }
 
@@ -358,7 +382,7 @@ template <class T, class S, int F, bool SPLIT, int PM = 1> constexpr size_t lds_
 
 // SRC_IN_LDS: `src` reads the same LDS buffer the exchanges use (Rader/Bluestein second transform), so a
 // barrier separates the loads from the first scatter.
-template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, bool SRC_IN_LDS = false, int PM = 1, int ABL = 0, int TWREG = -1, class X, class SRC, class DST>
+template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, bool SRC_IN_LDS = false, int PM = 1, int ABL = 0, int TWREG = -1, bool TWSTAGE = false, class X, class SRC, class DST>
 MI_HD void wg_fft(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC src, DST dst) {
     static_assert(S::valid(), "radices must multiply to N");
     constexpr int R0 = S::R[0], NB0 = S::nb(0), BPT0 = S::bpt(0);
@@ -376,7 +400,7 @@ MI_HD void wg_fft(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC src, DS
         });
     });
     if constexpr (SRC_IN_LDS) ex.barrier();
-    wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, 0, TWREG>(ex, lds_raw, tw, src, dst);
+    wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, 0, TWREG, TWSTAGE>(ex, lds_raw, tw, src, dst);
 }
 
 }  // namespace mi355

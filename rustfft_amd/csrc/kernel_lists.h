@@ -31,8 +31,7 @@
     MI_BS(T, PREC, 8, 512, 32, 16, 8, 4);          \
     MI_BS(T, PREC, 4, 1024, 64, 16, 16, 4);        \
     MI_BS(T, PREC, 2, 2048, 128, 16, 16, 8);       \
-    MI_BS(T, PREC, 1, 4096, 256, 16, 16, 16);      \
-    MI_BS(T, PREC, 1, 8192, 512, 16, 8, 8, 8)
+    MI_BS(T, PREC, 1, 4096, 256, 16, 16, 16)
 
 // Bluestein bodies over the 3 * 2^k inner lengths (the reference's second family, src/plan.rs:649-657): the planner takes
 // the smallest compiled M >= 2n - 1, so the worst-case padding drops from 2x to 1.33x
@@ -42,19 +41,19 @@
     MI_BS(T, PREC, 64, 48, 4, 12, 4);  \
     MI_BS(T, PREC, 32, 96, 8, 16, 6);  \
     MI_BS(T, PREC, 16, 192, 16, 16, 12);  \
-    MI_BS(T, PREC, 10, 384, 26, 16, 8, 3);  \
-    MI_BS(T, PREC, 5, 768, 52, 16, 16, 3);  \
+    MI_BS(T, PREC, 8, 384, 32, 12, 8, 4);  \
+    MI_BS(T, PREC, 2, 768, 96, 8, 8, 12);  \
     MI_BS(T, PREC, 2, 1536, 128, 16, 16, 6);  \
     MI_BS(T, PREC, 1, 3072, 256, 16, 16, 12);  \
-    MI_BS(T, PREC, 1, 6144, 512, 16, 16, 12, 2)
+    MI_BS(T, PREC, 1, 6144, 512, 16, 16, 24)
 #define MI_BS_LIST3_F64(T, PREC)                  \
     MI_BS(T, PREC, 256, 12, 1, 12);  \
     MI_BS(T, PREC, 128, 24, 2, 12, 2);  \
     MI_BS(T, PREC, 64, 48, 4, 12, 4);  \
     MI_BS(T, PREC, 32, 96, 8, 16, 6);  \
     MI_BS(T, PREC, 16, 192, 16, 16, 12);  \
-    MI_BS(T, PREC, 8, 384, 26, 16, 8, 3);  \
-    MI_BS(T, PREC, 4, 768, 52, 16, 16, 3);  \
+    MI_BS(T, PREC, 4, 384, 32, 12, 8, 4);  \
+    MI_BS(T, PREC, 2, 768, 96, 8, 8, 12);  \
     MI_BS(T, PREC, 2, 1536, 128, 16, 16, 6);  \
     MI_BS(T, PREC, 1, 3072, 256, 16, 16, 12);  \
-    MI_BS(T, PREC, 1, 6144, 512, 16, 16, 12, 2)
+    MI_BS(T, PREC, 1, 6144, 512, 16, 16, 24)

@@ -220,36 +220,37 @@ template <class T, class S, int F, class X>
 MI_HD void bluestein_body(X& ex, const BluesteinParams<T>& p, long long block, void* lds) {
     constexpr int M = S::N, PITCH = S::pitch();
     const long long fft0 = block * F;
-    const cx<T>* MI_RESTRICT in = p.in;
-    cx<T>* MI_RESTRICT out = p.out;
+    // uniform row base + 32-bit offsets: one address register per access instead of a 64-bit pair
+    const cx<T>* MI_RESTRICT in = p.in + fft0 * p.n;
+    cx<T>* MI_RESTRICT out = p.out + fft0 * p.n;
     const cx<T>* MI_RESTRICT chirp = p.chirp;
     const cx<T>* MI_RESTRICT bf = p.bf;
-    const long long batch = p.batch;
+    const int rows = (int)((p.batch - fft0) < F ? (p.batch - fft0) : F);
     const int n = p.n;
     const T sgn = p.sgn;
     cx<T>* work = (cx<T>*)lds;  // natural-order spectrum; reuses the exchange buffer once the first transform is done
     auto src1 = [=](int f, int i) -> cx<T> {
-        const long long g = fft0 + f;
-        if (g < batch && i < n) {
-            cx<T> x = in[g * n + i];
+        if (f < rows && i < n) {
+            cx<T> x = in[(unsigned)(f * n + i)];
             x.im *= sgn;
-            return x * chirp[i];
+            return x * chirp[(unsigned)i];
         }
         return cx<T>{0, 0};
     };
-    auto dst1 = [=](int f, int j, cx<T> v) { work[f * PITCH + j] = cconj(v * bf[j]); };
-    wg_fft<T, S, F, MAP_EF, MAP_EF, false>(ex, lds, p.tw, elem_src(src1), dst1);
+    auto dst1 = [=](int f, int j, cx<T> v) { work[f * PITCH + j] = cconj(v * bf[(unsigned)j]); };
+    constexpr bool BS_STAGE = false;
+    constexpr int TW0 = BS_STAGE ? S::emax() : -1;  // staging registers for the next sub-pass's twiddles (engine.h TWSTAGE)
+    wg_fft<T, S, F, MAP_EF, MAP_EF, false, false, 1, 0, TW0, BS_STAGE>(ex, lds, p.tw, elem_src(src1), dst1);
     ex.barrier();
     auto src2 = [=](int f, int i) -> cx<T> { return work[f * PITCH + i]; };
     auto dst2 = [=](int f, int j, cx<T> v) {
-        const long long g = fft0 + f;
-        if (g < batch && j < n) {
-            cx<T> y = cconj(v) * chirp[j];
+        if (f < rows && j < n) {
+            cx<T> y = cconj(v) * chirp[(unsigned)j];
             y.im *= sgn;
-            out[g * n + j] = y;
+            out[(unsigned)(f * n + j)] = y;
         }
     };
-    wg_fft<T, S, F, MAP_EF, MAP_EF, false, true>(ex, lds, p.tw, elem_src(src2), dst2);
+    wg_fft<T, S, F, MAP_EF, MAP_EF, false, true, 1, 0, TW0, BS_STAGE>(ex, lds, p.tw, elem_src(src2), dst2);
     (void)M;
 }
 

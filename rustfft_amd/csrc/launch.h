@@ -90,7 +90,7 @@ template <class T, class S, int F, bool FIRST, bool SPLIT, int ABL = 0> KernelEn
 template <class T, class S, int F>
 __global__ __launch_bounds__(F* S::TPF) void bluestein_kernel(BluesteinParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    DevExec<T, regs_needed<S, false>()> ex;
+    DevExec<T, regs_needed<S, false>() + twreg_count<S>()> ex;
     bluestein_body<T, S, F>(ex, p, (long long)blockIdx.x, smem);
 }
 template <class T, class S, int F, int MODE>
@@ -331,7 +331,7 @@ template <class T, class S, int F> KernelEntry make_bluestein(int prec, const ch
     e.launch = [](const void* params, long long grid, void*) {
         std::vector<char> lds(bluestein_lds<T, S, F>() + 64, (char)0x5a);
         for (long long b = 0; b < grid; ++b) {
-            HostExec<T, regs_needed<S, false>()> ex(F * S::TPF);
+            HostExec<T, regs_needed<S, false>() + twreg_count<S>()> ex(F * S::TPF);
             bluestein_body<T, S, F>(ex, *(const BluesteinParams<T>*)params, b, lds.data());
         }
     };
@@ -450,7 +450,11 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
 #define MI_K2G(T, PREC, F, ...)                                                                        \
     reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, true>(PREC, "k2gfirst<" #__VA_ARGS__ ">xF" #F));  \
     reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, false>(PREC, "k2glater<" #__VA_ARGS__ ">xF" #F))
-#define MI_BS(T, PREC, F, ...) reg.push_back(make_bluestein<T, Sched<__VA_ARGS__>, F>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F))
+// Bluestein bodies take the linear exchange layout (SchedL): 164 -> 124 VGPRs for the power-of-two inner lengths
+#define MI_BS(T, PREC, F, ...) reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F))
+#define MI_BSV(V, T, PREC, F, ...)                                                                    \
+    reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F "v" #V)); \
+    reg.back().variant = V
 #define MI_RADER(T, PREC, F, MODE, ...) reg.push_back(make_rader<T, Sched<__VA_ARGS__>, F, MODE>(PREC, "rader<" #__VA_ARGS__ ">xF" #F "m" #MODE))
 #define MI_RADERV(V, T, PREC, F, MODE, ...)                                                                   \
     reg.push_back(make_rader<T, Sched<__VA_ARGS__>, F, MODE>(PREC, "rader<" #__VA_ARGS__ ">xF" #F "m" #MODE "v" #V)); \

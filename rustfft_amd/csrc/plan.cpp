@@ -554,7 +554,10 @@ template <class T> static int build_plan_t(Plan& plan) {
     {
         const KernelEntry* best = nullptr;
         for (auto& e : registry())
-            if (e.kind == KIND_BLUESTEIN && e.prec == plan.prec && (size_t)e.n >= 2 * n - 1 && (!best || e.n < best->n)) best = &e;
+            if (e.kind == KIND_BLUESTEIN && e.prec == plan.prec && e.variant == 0 && (size_t)e.n >= 2 * n - 1 && (!best || e.n < best->n)) best = &e;
+        if (best && env_int("MI355FFT_VARIANT"))  // tuning: an alternative body for the same inner length
+            for (auto& e : registry())
+                if (e.kind == KIND_BLUESTEIN && e.prec == plan.prec && e.n == best->n && e.variant == env_int("MI355FFT_VARIANT")) best = &e;
         if (best) {
             if (best->prepare()) return MI355FFT_ERR_HIP;
             const size_t M = best->n;
