@@ -45,15 +45,23 @@ void register_k2g_f64_0(std::vector<KernelEntry>&);
 void register_k2g_f64_1(std::vector<KernelEntry>&);
 void register_k2g_f64_2(std::vector<KernelEntry>&);
 void register_k2g_f64_3(std::vector<KernelEntry>&);
-// generated: compiled schedules for the 7-smooth lengths in (16, 4096] (tools/gen_smooth_kernels.py)
+// generated: compiled schedules for the 13-smooth lengths in (16, 4096] (tools/gen_smooth_kernels.py)
 void register_smooth_f32_0(std::vector<KernelEntry>&);
 void register_smooth_f32_1(std::vector<KernelEntry>&);
 void register_smooth_f32_2(std::vector<KernelEntry>&);
 void register_smooth_f32_3(std::vector<KernelEntry>&);
+void register_smooth_f32_4(std::vector<KernelEntry>&);
+void register_smooth_f32_5(std::vector<KernelEntry>&);
+void register_smooth_f32_6(std::vector<KernelEntry>&);
+void register_smooth_f32_7(std::vector<KernelEntry>&);
 void register_smooth_f64_0(std::vector<KernelEntry>&);
 void register_smooth_f64_1(std::vector<KernelEntry>&);
 void register_smooth_f64_2(std::vector<KernelEntry>&);
 void register_smooth_f64_3(std::vector<KernelEntry>&);
+void register_smooth_f64_4(std::vector<KernelEntry>&);
+void register_smooth_f64_5(std::vector<KernelEntry>&);
+void register_smooth_f64_6(std::vector<KernelEntry>&);
+void register_smooth_f64_7(std::vector<KernelEntry>&);
 
 template <class S> inline void fill_sched(KernelEntry& e) {
     e.tpf = S::TPF;
