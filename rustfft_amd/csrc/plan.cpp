@@ -38,10 +38,18 @@ void ensure_registry() {
         register_k2g_f32_1(r);
         register_k2g_f32_2(r);
         register_k2g_f32_3(r);
+        register_k2g_f32_4(r);
+        register_k2g_f32_5(r);
+        register_k2g_f32_6(r);
+        register_k2g_f32_7(r);
         register_k2g_f64_0(r);
         register_k2g_f64_1(r);
         register_k2g_f64_2(r);
         register_k2g_f64_3(r);
+        register_k2g_f64_4(r);
+        register_k2g_f64_5(r);
+        register_k2g_f64_6(r);
+        register_k2g_f64_7(r);
         register_smooth_f32_0(r);
         register_smooth_f32_1(r);
         register_smooth_f32_2(r);
@@ -157,18 +165,50 @@ static void host_dft(std::vector<cd>& a) {
         }
         return;
     }
-    std::vector<cd> out(n);
-    for (size_t k = 0; k < n; ++k) {
-        cd acc(0, 0);
-        size_t idx = 0;
-        for (size_t j = 0; j < n; ++j) {
-            acc += a[j] * w[idx];
-            idx += k;
-            if (idx >= n) idx -= n;
+    // any other length: decimation in time by the smallest prime factor, O(n * sum of prime factors); the roots always
+    // come from the exact table of the full length
+    struct Rec {
+        static std::vector<cd> go(const std::vector<cd>& x, const std::vector<cd>& w) {
+            const size_t n = x.size(), N = w.size(), scale = N / n;
+            if (n == 1) return x;
+            size_t p = n;
+            for (size_t d = 2; d * d <= n; ++d)
+                if (n % d == 0) {
+                    p = d;
+                    break;
+                }
+            std::vector<cd> out(n);
+            if (p == n) {  // prime: the definition
+                for (size_t k = 0; k < n; ++k) {
+                    cd acc(0, 0);
+                    size_t idx = 0;
+                    for (size_t j = 0; j < n; ++j) {
+                        acc += x[j] * w[idx * scale];
+                        idx += k;
+                        if (idx >= n) idx -= n;
+                    }
+                    out[k] = acc;
+                }
+                return out;
+            }
+            const size_t m = n / p;
+            std::vector<std::vector<cd>> y(p);
+            std::vector<cd> sub(m);
+            for (size_t r = 0; r < p; ++r) {
+                for (size_t j = 0; j < m; ++j) sub[j] = x[r + p * j];
+                y[r] = go(sub, w);
+            }
+            for (size_t q = 0; q < p; ++q)
+                for (size_t k = 0; k < m; ++k) {
+                    const size_t kk = k + m * q;
+                    cd acc = y[0][k];
+                    for (size_t r = 1; r < p; ++r) acc += y[r][k] * w[((r * kk) % n) * scale];
+                    out[kk] = acc;
+                }
+            return out;
         }
-        out[k] = acc;
-    }
-    a.swap(out);
+    };
+    a = Rec::go(a, w);
 }
 template <class T> static std::vector<T> to_interleaved(const std::vector<cd>& v) {
     std::vector<T> o;
@@ -431,7 +471,7 @@ template <class T> static int build_plan_t(Plan& plan) {
         }
         return MI355FFT_OK;
     }
-    // composite lengths above one workgroup whose factors are 2, 3, 5: two to four general passes (k2g_body)
+    // composite lengths above one workgroup whose factors are 2, 3, 5, 7: two to four general passes (k2g_body)
     if (n > 4096 && n < ((size_t)1 << 31) && choose_general_radices(plan.prec, n, radices)) {
         plan.kind = PLAN_MACRO;
         size_t s = 1;
@@ -595,6 +635,23 @@ template <class T> static int build_plan_t(Plan& plan) {
     {
         size_t M = 1;
         while (M < 2 * n - 1) M <<= 1;
+        // a 7-smooth M between 2n - 1 and that power of two pads less (every pass of the pipeline runs over M, not n):
+        // take the smallest one the general passes cover in no more kernels than the power of two needs
+        if (M < ((size_t)1 << 31) && env_int("MI355FFT_BLUESTEIN_POW2") == 0) {
+            std::vector<size_t> r0, r1, cand;
+            const size_t p0 = choose_macro_radices(plan.prec, M, r0) ? r0.size() : 4;
+            for (size_t a = 1; a < M; a *= 2)
+                for (size_t b = a; b < M; b *= 3)
+                    for (size_t c = b; c < M; c *= 5)
+                        for (size_t d = c; d < M; d *= 7)
+                            if (d >= 2 * n - 1 && d > 4096) cand.push_back(d);
+            std::sort(cand.begin(), cand.end());
+            for (size_t c : cand)
+                if (c * 20 <= M * 17 && choose_general_radices(plan.prec, c, r1) && r1.size() <= p0) {  // >= 15 % smaller: the general passes run ~10 % below the power-of-two tiles
+                    M = c;
+                    break;
+                }
+        }
         const KernelEntry* pw = nullptr;
         for (auto& e : registry())
             if (e.kind == KIND_POINTWISE && e.prec == plan.prec) pw = &e;
@@ -775,7 +832,7 @@ template <class T> static int execute_t(Plan& plan, const void* in, void* out, s
         const size_t M = plan.inner->len;
         const PassDesc& pd = plan.passes[0];
         const bool inverse = plan.direction == MI355FFT_INVERSE;
-        size_t chunk = std::max<size_t>(1, ((size_t)1 << 29) / (M * esz));  // <= 512 MiB of padded rows at a time
+        size_t chunk = std::max<size_t>(1, ((size_t)1 << 31) / (M * esz));  // <= 2 GiB of padded rows at a time
         if (chunk > batch) chunk = batch;
         char* ws = (char*)plan.workspace_for(stream, chunk * M * esz);
         if (!ws) return MI355FFT_ERR_OUT_OF_MEMORY;

@@ -36,15 +36,23 @@ void register_k2_f32(std::vector<KernelEntry>&);
 void register_k2_f64(std::vector<KernelEntry>&);
 void register_np2_f32(std::vector<KernelEntry>&);  // non-power-of-two: mixed radix, Rader, Bluestein
 void register_np2_f64(std::vector<KernelEntry>&);
-// generated: large-N pass kernels for 5-smooth tile heights (tools/gen_k2g_kernels.py)
+// generated: large-N pass kernels for 7-smooth tile heights (tools/gen_k2g_kernels.py)
 void register_k2g_f32_0(std::vector<KernelEntry>&);
 void register_k2g_f32_1(std::vector<KernelEntry>&);
 void register_k2g_f32_2(std::vector<KernelEntry>&);
 void register_k2g_f32_3(std::vector<KernelEntry>&);
+void register_k2g_f32_4(std::vector<KernelEntry>&);
+void register_k2g_f32_5(std::vector<KernelEntry>&);
+void register_k2g_f32_6(std::vector<KernelEntry>&);
+void register_k2g_f32_7(std::vector<KernelEntry>&);
 void register_k2g_f64_0(std::vector<KernelEntry>&);
 void register_k2g_f64_1(std::vector<KernelEntry>&);
 void register_k2g_f64_2(std::vector<KernelEntry>&);
 void register_k2g_f64_3(std::vector<KernelEntry>&);
+void register_k2g_f64_4(std::vector<KernelEntry>&);
+void register_k2g_f64_5(std::vector<KernelEntry>&);
+void register_k2g_f64_6(std::vector<KernelEntry>&);
+void register_k2g_f64_7(std::vector<KernelEntry>&);
 // generated: compiled schedules for the 13-smooth lengths in (16, 4096] (tools/gen_smooth_kernels.py)
 void register_smooth_f32_0(std::vector<KernelEntry>&);
 void register_smooth_f32_1(std::vector<KernelEntry>&);

@@ -300,11 +300,11 @@ def test_lengths_beyond_one_workgroup(planners, oracle, dtype):
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_general_column_tile_passes(planners, oracle, dtype):
-    """5-smooth lengths above one workgroup run as 2-4 general column-tile passes (k2g kernels): tile heights that
+    """7-smooth lengths above one workgroup run as 2-4 general column-tile passes (k2g kernels): tile heights that
     do not divide the strides, ragged last tiles, powers of 3 and 5, ragged batches; vs the oracle's planner choice
     (RadixN / MixedRadix, src/plan.rs:430-560) up to 10^5, vs numpy complex128 beyond."""
     planner = planners[np.dtype(dtype)]
-    for n in (5000, 6000, 8000, 10000, 12000, 19683, 78125, 98304, 100000, 13122, 150000, 1000000, 1536000, 3 << 20, 5 << 21):
+    for n in (5000, 5488, 6000, 8000, 10000, 12000, 14000, 19683, 44100, 78125, 98304, 100000, 117649, 13122, 150000, 1000000, 1536000, 3 << 20, 5 << 21, 7 << 20):
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
             assert fft.describe().startswith("k2gfirst"), (n, fft.describe())
@@ -333,7 +333,7 @@ def test_runtime_scheduled_kernels(planners, oracle, dtype):
     """13-smooth lengths (run-time scheduled mixed radix, the RadixN analogue) and primes with 13-smooth p - 1
     (run-time scheduled Rader) vs the oracle's planner choice, all four API modes."""
     planner = planners[np.dtype(dtype)]
-    for n in [3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 4116, 4368, 4459, 4620, 5005]:
+    for n in [3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 4368, 4459, 4620, 5005]:
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
             assert "dyn_k1" in fft.describe(), (n, fft.describe())

@@ -188,11 +188,11 @@ def test_lengths_beyond_one_workgroup(emu_planner, oracle, dtype):
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_general_column_tile_passes(emu_planner, oracle, dtype):
-    """5-smooth lengths above one workgroup (kernels.h k2g_body): 2, 3 and 4 passes, tile heights that do not divide
+    """7-smooth lengths above one workgroup (kernels.h k2g_body): 2, 3 and 4 passes, tile heights that do not divide
     the strides (per-column b mod s), ragged last tiles (M not a multiple of F), pure powers of 3 and 5.  The
     reference plans these as RadixN / MixedRadix (src/plan.rs:430-560)."""
     planner = emu_planner(dtype)
-    for n, npass in ((5000, 2), (6000, 2), (10000, 2), (19683, 2), (78125, 2), (98304, 2), (100000, 2), (1000000, 3)):
+    for n, npass in ((5000, 2), (5488, 2), (6000, 2), (10000, 2), (19683, 2), (44100, 2), (78125, 2), (98304, 2), (100000, 2), (1000000, 3)):
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
             desc = fft.describe()
@@ -206,7 +206,7 @@ def test_runtime_scheduled_kernels(emu_planner, oracle, dtype):
     src/algorithm/radixn.rs:497-541 covers factors 2..7 over small bases; here every compiled radix appears) and
     primes with 13-smooth p - 1 through the run-time scheduled Rader (raders_algorithm.rs:302-309: primes < 100)."""
     planner = emu_planner(dtype)
-    smooth = [3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 4116, 4368, 4459, 4620, 5005]
+    smooth = [3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 4368, 4459, 4620, 5005]
     for n in smooth:
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
