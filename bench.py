@@ -23,6 +23,22 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def copy_ceiling_gbps(torch, nbytes=1 << 31):
+    """Attainable HBM rate of this box for a plain device copy (read + write bytes / time): SURVEY.md section 8(d) asks for
+    the roofline fraction against both the 8 TB/s spec and the measured copy bandwidth."""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device="cuda")
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def cpu_baseline(n, log):
     """Oracle (C++ restatement of RustFFT's scalar path, kind="port") timed on this box's host cores:
     every core owns a slice of the sample batch and shares one plan (examples/concurrency.rs:9-30)."""
@@ -208,6 +224,11 @@ def main():
                            "algorithmic_bytes_per_launch": alg_bytes,
                            "kernels": per_kernel,
                            "transform_algorithmic_frac": (batch * 2 * n * 8) / (sum(r["ms"] for r in per_kernel) * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        try:
+            cc = copy_ceiling_gbps(torch)
+            out["roofline"]["copy_ceiling"] = {"GBps": cc, "frac_of_copy": dom["GBps"] / cc, "what": "torch device-to-device copy of 2 GiB, read + write bytes"}
+        except Exception as e:
+            log(f"copy ceiling unavailable: {e}")
         if world == 1 and not args.no_pmc:
             # HBM bytes per launch of the dominant kernel from PMC counters (two extra short rocprofv3 runs)
             try:

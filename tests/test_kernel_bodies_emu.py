@@ -206,7 +206,7 @@ def test_runtime_scheduled_kernels(emu_planner, oracle, dtype):
     src/algorithm/radixn.rs:497-541 covers factors 2..7 over small bases; here every compiled radix appears) and
     primes with 13-smooth p - 1 through the run-time scheduled Rader (raders_algorithm.rs:302-309: primes < 100)."""
     planner = emu_planner(dtype)
-    smooth = [3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 4368, 4459, 4620, 5005]
+    smooth = [4368, 4459, 4620, 5005]
     for n in smooth:
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
@@ -229,12 +229,12 @@ def _thirteen_smooth(limit):
     s = {1}
     for p in (2, 3, 5, 7, 11, 13):
         s = {v * p**k for v in s for k in range(0, 13) if v * p**k <= limit}
-    return sorted(v for v in s if v > 16 and (v & (v - 1)))
+    return sorted(v for v in s if v > 2 and (v & (v - 1)))
 
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_compiled_smooth_schedules(emu_planner, dtype):
-    """Every 13-smooth length in (16, 4096] has its own compiled schedule (tools/gen_smooth_kernels.py — the lengths the
+    """Every 13-smooth length in [3, 4096] has its own compiled schedule (tools/gen_smooth_kernels.py — the lengths the
     reference plans as RadixN, src/plan.rs:508-607): forward and inverse, ragged batch, vs numpy in float64."""
     planner = emu_planner(dtype)
     tol = 1e-6 if dtype == np.complex64 else 1e-14
