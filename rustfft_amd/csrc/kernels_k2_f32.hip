@@ -13,8 +13,11 @@ void register_k2_f32(std::vector<KernelEntry>& reg) {
     // 1024-row tile: 16 columns (128-byte row segments), 32 values per thread, real/imaginary planes exchanged
     // one after the other so two workgroups fit a CU's LDS; the twiddled sub-passes are radix 8 (fewer live twiddles)
     MI_K2(float, 32, 16, true, 1024, 32, 8, 8, 16);
-    // 2048-row tile (2^21 and 2^22 in two passes instead of three): 8 columns = 64-byte row segments, tiles paired per XCD
-    MI_K2(float, 32, 8, true, 2048, 64, 8, 16, 16);
+    // 2048-row tile (2^21 and 2^22 in two passes instead of three): 16 columns = 128-byte row segments through the split
+    // exchange (135 KB of LDS, one 1024-thread workgroup per CU).  Measured at 2^22: 14.0 TFLOP/s against 13.0 for the
+    // 8-column tile (64-byte segments, two workgroups per CU, tiles paired per XCD), kept as variant 2.
+    MI_K2(float, 32, 16, true, 2048, 64, 8, 16, 16);
+    MI_K2V(2, float, 32, 8, true, 2048, 64, 8, 16, 16);
     MI_K2V(1, float, 32, 8, false, 1024, 64, 16, 16, 4);   // tuning: 64-byte row segments paired per XCD, full-complex exchange
     MI_K2V(3, float, 32, 8, true, 1024, 32, 8, 8, 16);     // tuning: 8-column tiles (paired per XCD), 256 threads, four workgroups per CU
     // ablation probes of the default 1024-row tile (wrong results by design; MI355FFT_VARIANT=5..8, tuning only)
