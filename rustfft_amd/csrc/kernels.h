@@ -152,13 +152,18 @@ MI_HD void k2_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
 // not be a multiple of F: columns >= M are masked) and a tile may straddle a multiple of S (B div S and B mod S are
 // taken per column).  This is the GPU form of the reference's generic MixedRadix (src/algorithm/mixed_radix.rs:128-158)
 // for composite lengths; the power-of-two plans keep the specialised body above.
-template <class T, bool FIRST> struct K2gSrc {
+// FUSE (multi-kernel Bluestein, bluesteins_algorithm.rs:100-136): 1 = the FIRST pass reads the caller's rows (pitch n),
+// multiplies by the chirp and zero-pads on the fly; 2 = the last pass stores conj(X * bf); 3 = the last pass stores
+// conj(X) * chirp, truncated to n, into the caller's rows.  0 = plain pass.
+template <class T, bool FIRST, int FUSE = 0> struct K2gSrc {
     const cx<T>* MI_RESTRICT in;
     unsigned M, S, b0;
     T sgn_in;
     const cx<T>* MI_RESTRICT tlo;
     const cx<T>* MI_RESTRICT thi;
     int hshift, lmask;
+    const cx<T>* MI_RESTRICT tab;
+    unsigned n_valid;
     MI_HD cx<T> lut(unsigned e) const { return tlo[e & (unsigned)lmask] * thi[e >> hshift]; }
     template <int R, int LOG, int K, int J0> MI_HD static void apply_tw(cx<T>* v, cx<T> w, const cx<T>* sp) {
         v[K] = v[K] * w;
@@ -172,9 +177,20 @@ template <class T, bool FIRST> struct K2gSrc {
         const unsigned col = B < M ? B : 0;  // masked columns read column 0 (never stored)
         static_for<0, R>([&](auto K_) {
             constexpr int k = K_;
-            cx<T> x = in[col + (unsigned)(b + k * nb) * M];
-            x.im *= sgn_in;
-            v[k] = x;
+            const unsigned idx = col + (unsigned)(b + k * nb) * M;
+            if constexpr (FUSE == 1) {
+                cx<T> x = cx<T>{0, 0};
+                if (idx < n_valid) {
+                    x = in[idx];
+                    x.im *= sgn_in;
+                    x = x * tab[idx];
+                }
+                v[k] = x;
+            } else {
+                cx<T> x = in[idx];
+                x.im *= sgn_in;
+                v[k] = x;
+            }
         });
         if constexpr (!FIRST) {
             const unsigned c = col % S;
@@ -192,24 +208,40 @@ template <class T, bool FIRST> struct K2gSrc {
     }
 };
 
-template <class T, class S, int F, bool FIRST, class X>
+template <class T, class S, int F, bool FIRST, int FUSE, class X>
 MI_HD void k2g_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
+    static_assert(FUSE == 0 || (FUSE == 1) == FIRST, "chirp-in fuses into a first pass, the output stages into a last pass");
     constexpr int R = S::N;
     const long long g = block / p.tiles_per_fft;
     const unsigned b0 = (unsigned)(block % p.tiles_per_fft) * (unsigned)F;
-    const cx<T>* MI_RESTRICT in = p.in + g * p.n;
-    cx<T>* MI_RESTRICT out = p.out + g * p.n;
+    const cx<T>* MI_RESTRICT in = p.in + g * (FUSE == 1 ? p.n_io : p.n);
+    cx<T>* MI_RESTRICT out = p.out + g * (FUSE == 3 ? p.n_io : p.n);
     const unsigned M = (unsigned)p.m, Sg = (unsigned)p.s;
     const T sgn_out = p.sgn_out;
-    K2gSrc<T, FIRST> src{in, M, Sg, b0, p.sgn_in, p.tlo, p.thi, p.hshift, p.lmask};
+    const cx<T>* MI_RESTRICT tab = p.tab;
+    const unsigned n_valid = p.n_valid;
+    K2gSrc<T, FIRST, FUSE> src{in, M, Sg, b0, p.sgn_in, p.tlo, p.thi, p.hshift, p.lmask, tab, n_valid};
     auto dst = [=](int f, int k, cx<T> x) {
         const unsigned B = b0 + (unsigned)f;
         if (B < M) {
-            x.im *= sgn_out;
-            if constexpr (FIRST)
+            if constexpr (FIRST) {
+                x.im *= sgn_out;
                 out[B * (unsigned)R + (unsigned)k] = x;
-            else
-                out[(B / Sg) * (Sg * (unsigned)R) + (B % Sg) + (unsigned)k * Sg] = x;
+            } else {
+                const unsigned e = (B / Sg) * (Sg * (unsigned)R) + (B % Sg) + (unsigned)k * Sg;
+                if constexpr (FUSE == 2) {
+                    out[e] = cconj(x * tab[e]);
+                } else if constexpr (FUSE == 3) {
+                    if (e < n_valid) {
+                        cx<T> y = cconj(x) * tab[e];
+                        y.im *= sgn_out;
+                        out[e] = y;
+                    }
+                } else {
+                    x.im *= sgn_out;
+                    out[e] = x;
+                }
+            }
         }
     };
     wg_fft<T, S, F, MAP_FF, FIRST ? MAP_EF : MAP_FF, false, false, k2_pitch_mod(F)>(ex, lds, p.tw, src, dst);

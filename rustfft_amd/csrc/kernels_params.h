@@ -29,6 +29,11 @@ template <class T> struct K2Params {
     T sgn_in, sgn_out;
     int pair;  // tiles per 128-byte line (XCD-aware ordering), 1 = identity
     int dbg;   // measurement knobs (bit 0: skip the inter-pass twiddles); 0 in production
+    // fused multi-kernel Bluestein (k2g_body FUSE != 0): the element-wise stages of bluesteins_algorithm.rs:100-136 ride
+    // on the first load / last store of the two inner transforms
+    const cx<T>* tab;   // FUSE 1, 3: chirp[n_valid]; FUSE 2: spectrum multiplier bf[N]
+    long long n_io;     // FUSE 1: row pitch of `in`; FUSE 3: row pitch of `out` (the caller's length n, not N)
+    unsigned n_valid;   // FUSE 1: elements >= n_valid of a row are zero padding; FUSE 3: only elements < n_valid are stored
 };
 
 // Bluestein (chirp-z) in one workgroup, src/algorithm/bluesteins_algorithm.rs:100-136:

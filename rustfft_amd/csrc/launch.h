@@ -171,15 +171,15 @@ template <class T, class S, int F, int MODE> KernelEntry make_rader(int prec, co
     };
     return e;
 }
-template <class T, class S, int F, bool FIRST>
+template <class T, class S, int F, bool FIRST, int FUSE>
 __global__ __launch_bounds__(F* S::TPF) void k2g_kernel(K2Params<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevExec<T, regs_needed<S, false>()> ex;
-    k2g_body<T, S, F, FIRST>(ex, p, (long long)blockIdx.x, smem);
+    k2g_body<T, S, F, FIRST, FUSE>(ex, p, (long long)blockIdx.x, smem);
 }
-template <class T, class S, int F, bool FIRST> KernelEntry make_k2g(int prec, const char* name) {
+template <class T, class S, int F, bool FIRST, int FUSE = 0> KernelEntry make_k2g(int prec, const char* name) {
     KernelEntry e{};
-    e.kind = FIRST ? KIND_K2G_FIRST : KIND_K2G_LATER;
+    e.kind = FUSE == 1 ? KIND_K2G_FIRST_CHIRP : FUSE == 2 ? KIND_K2G_LAST_MUL : FUSE == 3 ? KIND_K2G_LAST_CHIRP : FIRST ? KIND_K2G_FIRST : KIND_K2G_LATER;
     e.prec = prec;
     e.n = S::N;
     e.f = F;
@@ -189,11 +189,11 @@ template <class T, class S, int F, bool FIRST> KernelEntry make_k2g(int prec, co
     e.name = name;
     e.launch = [](const void* params, long long grid, void* stream) {
         void* args[] = {const_cast<void*>(params)};
-        (void)hipLaunchKernel((const void*)k2g_kernel<T, S, F, FIRST>, dim3((unsigned)grid), dim3(F * S::TPF), args,
+        (void)hipLaunchKernel((const void*)k2g_kernel<T, S, F, FIRST, FUSE>, dim3((unsigned)grid), dim3(F * S::TPF), args,
                               lds_bytes<T, S, F, false, k2_pitch_mod(F)>(), (hipStream_t)stream);
     };
     e.prepare = []() -> int {
-        return (int)hipFuncSetAttribute((const void*)k2g_kernel<T, S, F, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        return (int)hipFuncSetAttribute((const void*)k2g_kernel<T, S, F, FIRST, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds_bytes<T, S, F, false, k2_pitch_mod(F)>());
     };
     return e;
@@ -365,9 +365,9 @@ template <class T, class S, int F, int MODE> KernelEntry make_rader(int prec, co
     e.prepare = []() -> int { return 0; };
     return e;
 }
-template <class T, class S, int F, bool FIRST> KernelEntry make_k2g(int prec, const char* name) {
+template <class T, class S, int F, bool FIRST, int FUSE = 0> KernelEntry make_k2g(int prec, const char* name) {
     KernelEntry e{};
-    e.kind = FIRST ? KIND_K2G_FIRST : KIND_K2G_LATER;
+    e.kind = FUSE == 1 ? KIND_K2G_FIRST_CHIRP : FUSE == 2 ? KIND_K2G_LAST_MUL : FUSE == 3 ? KIND_K2G_LAST_CHIRP : FIRST ? KIND_K2G_FIRST : KIND_K2G_LATER;
     e.prec = prec;
     e.n = S::N;
     e.f = F;
@@ -379,7 +379,7 @@ template <class T, class S, int F, bool FIRST> KernelEntry make_k2g(int prec, co
         std::vector<char> lds(lds_bytes<T, S, F, false, k2_pitch_mod(F)>() + 64, (char)0x5a);
         for (long long b = 0; b < grid; ++b) {
             HostExec<T, regs_needed<S, false>()> ex(F * S::TPF);
-            k2g_body<T, S, F, FIRST>(ex, *(const K2Params<T>*)params, b, lds.data());
+            k2g_body<T, S, F, FIRST, FUSE>(ex, *(const K2Params<T>*)params, b, lds.data());
         }
     };
     e.prepare = []() -> int { return 0; };
@@ -450,6 +450,11 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
 #define MI_K2G(T, PREC, F, ...)                                                                        \
     reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, true>(PREC, "k2gfirst<" #__VA_ARGS__ ">xF" #F));  \
     reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, false>(PREC, "k2glater<" #__VA_ARGS__ ">xF" #F))
+// the three fused passes of the multi-kernel Bluestein for one tile height
+#define MI_K2GF(T, PREC, F, ...)                                                                              \
+    reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, true, 1>(PREC, "k2gfirst_chirp<" #__VA_ARGS__ ">xF" #F)); \
+    reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, false, 2>(PREC, "k2glast_mul<" #__VA_ARGS__ ">xF" #F));   \
+    reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, false, 3>(PREC, "k2glast_chirp<" #__VA_ARGS__ ">xF" #F))
 // Bluestein bodies take the linear exchange layout (SchedL): 164 -> 124 VGPRs for the power-of-two inner lengths
 #define MI_BS(T, PREC, F, ...) reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F))
 #define MI_BSV(V, T, PREC, F, ...)                                                                    \

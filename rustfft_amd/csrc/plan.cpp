@@ -416,6 +416,89 @@ static bool choose_general_radices(int prec, size_t n, std::vector<size_t>& out)
     return true;
 }
 
+// Passes of one length-N transform over the general column-tile kernels; kinds[p] names the kernel family of pass p
+// (plain first / later, or one of the fused Bluestein passes).
+template <class T>
+static int append_general_passes(Plan& plan, size_t N, const std::vector<size_t>& radices, const std::vector<int>& kinds, void* tab_first,
+                                 void* tab_last) {
+    int rc = MI355FFT_OK;
+    size_t s = 1;
+    for (size_t p = 0; p < radices.size(); ++p) {
+        const size_t R = radices[p];
+        const KernelEntry* k = find_kernel(kinds[p], plan.prec, R);
+        if (!k) return MI355FFT_ERR_UNSUPPORTED;
+        if (k->prepare()) return MI355FFT_ERR_HIP;
+        PassDesc pd{};
+        pd.k = k;
+        pd.m = (long long)(N / R);
+        pd.s = (long long)s;
+        pd.row_n = (long long)N;
+        pd.d_aux1 = (p == 0) ? tab_first : (p + 1 == radices.size()) ? tab_last : nullptr;
+        pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(*k), &rc);
+        if (rc) return rc;
+        if (p > 0) {
+            const size_t Q = s * R;
+            int bits = 0;
+            while (((size_t)1 << bits) < Q) ++bits;
+            const int h = (bits + 1) / 2;
+            std::vector<T> lo, hi;
+            for (size_t e = 0; e < ((size_t)1 << h); ++e) push_tw<T>(lo, e, Q);
+            for (size_t q = 0; q <= ((Q - 1) >> h); ++q) push_tw<T>(hi, q << h, Q);
+            pd.hshift = h;
+            pd.lmask = (int)(((size_t)1 << h) - 1);
+            pd.d_tlo = upload<T>(plan, lo, &rc);
+            if (rc) return rc;
+            pd.d_thi = upload<T>(plan, hi, &rc);
+            if (rc) return rc;
+        }
+        plan.passes.push_back(pd);
+        s *= R;
+    }
+    return MI355FFT_OK;
+}
+
+// Inner length of the fused multi-kernel Bluestein: the smallest product of 2, 3 or 4 tile heights that have the fused
+// pass kernels (tools/gen_k2g_kernels.py FUSED) reaching 2n - 1; fewest passes first, most balanced split among equals.
+static bool choose_fused_radices(int prec, size_t need, std::vector<size_t>& out) {
+    std::vector<size_t> av;
+    for (auto& e : registry())
+        if (e.kind == KIND_K2G_FIRST_CHIRP && e.prec == prec && find_kernel(KIND_K2G_LAST_MUL, prec, e.n) &&
+            find_kernel(KIND_K2G_LAST_CHIRP, prec, e.n) && find_kernel(KIND_K2G_FIRST, prec, e.n) && find_kernel(KIND_K2G_LATER, prec, e.n))
+            av.push_back(e.n);
+    if (av.empty()) return false;
+    std::sort(av.begin(), av.end(), std::greater<size_t>());
+    for (int P = 2; P <= 4; ++P) {
+        size_t top = 1;
+        for (int i = 0; i < P; ++i) top *= av.front();
+        if (top < need) continue;
+        std::vector<size_t> best, cur;
+        size_t best_prod = 0;
+        struct Rec {
+            static void go(const std::vector<size_t>& av, size_t start, size_t prod, int left, size_t need, std::vector<size_t>& cur,
+                           std::vector<size_t>& best, size_t& best_prod) {
+                if (left == 0) {
+                    if (prod >= need && (best.empty() || prod < best_prod || (prod == best_prod && cur.front() < best.front()))) {
+                        best = cur;
+                        best_prod = prod;
+                    }
+                    return;
+                }
+                for (size_t i = start; i < av.size(); ++i) {
+                    cur.push_back(av[i]);
+                    go(av, i, prod * av[i], left - 1, need, cur, best, best_prod);
+                    cur.pop_back();
+                }
+            }
+        };
+        Rec::go(av, 0, 1, P, need, cur, best, best_prod);
+        if (!best.empty()) {
+            out = best;
+            return true;
+        }
+    }
+    return false;
+}
+
 template <class T> static int build_plan_t(Plan& plan) {
     const size_t n = plan.len;
     if (n <= 1) {
@@ -630,8 +713,36 @@ template <class T> static int build_plan_t(Plan& plan) {
             return MI355FFT_OK;
         }
     }
-    // any other length: multi-kernel Bluestein over a power-of-two plan of length M >= 2n - 1
-    // (bluesteins_algorithm.rs:58-136 with the inner FFT_M realised by the K1 / K2 kernels)
+    // any other length: multi-kernel Bluestein (bluesteins_algorithm.rs:58-136) with the inner FFT_M realised by the
+    // general column-tile passes and the three element-wise stages fused into their first load / last store
+    if (env_int("MI355FFT_BLUESTEIN_UNFUSED") == 0 && 2 * n - 1 < ((size_t)1 << 31) && choose_fused_radices(plan.prec, 2 * n - 1, radices)) {
+        size_t M = 1;
+        for (size_t r : radices) M *= r;
+        std::vector<cd> chirp = bluestein_chirp(n), bvec(M, cd(0, 0));
+        bvec[0] = std::conj(chirp[0]) / (double)M;
+        for (size_t i = 1; i < n; ++i) {
+            bvec[i] = std::conj(chirp[i]) / (double)M;
+            bvec[M - i] = bvec[i];
+        }
+        host_dft(bvec);
+        void* d_chirp = upload<T>(plan, to_interleaved<T>(chirp), &rc);
+        if (rc) return rc;
+        void* d_bf = upload<T>(plan, to_interleaved<T>(bvec), &rc);
+        if (rc) return rc;
+        const size_t P = radices.size();
+        std::vector<int> k1(P, KIND_K2G_LATER), k2(P, KIND_K2G_LATER);
+        k1[0] = KIND_K2G_FIRST_CHIRP;
+        k1[P - 1] = KIND_K2G_LAST_MUL;
+        k2[0] = KIND_K2G_FIRST;
+        k2[P - 1] = KIND_K2G_LAST_CHIRP;
+        rc = append_general_passes<T>(plan, M, radices, k1, d_chirp, d_bf);
+        if (rc) return rc;
+        rc = append_general_passes<T>(plan, M, radices, k2, nullptr, d_chirp);
+        if (rc) return rc;
+        plan.kind = PLAN_BLUESTEIN_FUSED;
+        return MI355FFT_OK;
+    }
+    // fallback (and MI355FFT_BLUESTEIN_UNFUSED=1): separate chirp / multiply kernels around an inner plan of length M >= 2n - 1
     {
         size_t M = 1;
         while (M < 2 * n - 1) M <<= 1;
@@ -694,6 +805,12 @@ std::string Plan::describe() const {
     if (kind == PLAN_TRIVIAL) s << "trivial(len=" << len << ")";
     if (kind == PLAN_BLUESTEIN_LARGE) {
         s << "bluestein_large(M=" << inner->len << ": " << inner->describe() << ")";
+        return s.str();
+    }
+    if (kind == PLAN_BLUESTEIN_FUSED) {
+        s << "bluestein_large(M=" << passes[0].row_n << " fused: ";
+        for (size_t i = 0; i < passes.size(); ++i) s << (i == 0 ? "" : (i == passes.size() / 2 ? " | " : " -> ")) << passes[i].k->name;
+        s << ")";
         return s.str();
     }
     for (size_t i = 0; i < passes.size(); ++i) {
@@ -797,11 +914,14 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         p.thi = (const cx<T>*)pd.d_thi;
         p.hshift = pd.hshift;
         p.lmask = pd.lmask;
-        p.n = (long long)plan.len;
+        p.n = pd.row_n ? pd.row_n : (long long)plan.len;
         p.m = pd.m;
         p.s = pd.s;
         p.batch = (long long)batch;
-        const bool general = (k.kind == KIND_K2G_FIRST || k.kind == KIND_K2G_LATER);
+        p.tab = (const cx<T>*)pd.d_aux1;  // fused Bluestein passes only
+        p.n_io = (long long)plan.len;
+        p.n_valid = (unsigned)plan.len;
+        const bool general = (k.kind == KIND_K2G_FIRST || k.kind == KIND_K2G_LATER || k.kind >= KIND_K2G_FIRST_CHIRP);
         p.tiles_per_fft = general ? (pd.m + k.f - 1) / k.f : pd.m / k.f;
         p.sgn_in = (inverse && pi == 0) ? (T)-1 : (T)1;
         p.sgn_out = (inverse && pi + 1 == plan.passes.size()) ? (T)-1 : (T)1;
@@ -826,6 +946,29 @@ template <class T> static int execute_t(Plan& plan, const void* in, void* out, s
     if (batch == 0 || n == 0) return MI355FFT_OK;
     if (plan.kind == PLAN_TRIVIAL) {  // len 1: the DFT is the identity (reference plans Dft(1), src/plan.rs:313-314)
         if (in != out && backend::d2d(out, in, batch * n * esz, stream)) return MI355FFT_ERR_HIP;
+        return MI355FFT_OK;
+    }
+    if (plan.kind == PLAN_BLUESTEIN_FUSED) {
+        // two transforms of length M, P passes each: caller rows -> A [-> B ...] -> (in place) | -> other [...] -> caller rows
+        const size_t M = (size_t)plan.passes[0].row_n, P = plan.passes.size() / 2;
+        size_t chunk = std::max<size_t>(1, ((size_t)1 << 31) / (M * esz));  // <= 2 x 2 GiB of padded rows at a time
+        if (chunk > batch) chunk = batch;
+        char* ws = (char*)plan.workspace_for(stream, 2 * chunk * M * esz);
+        if (!ws) return MI355FFT_ERR_OUT_OF_MEMORY;
+        char* bufs[2] = {ws, ws + chunk * M * esz};
+        for (size_t c0 = 0; c0 < batch; c0 += chunk) {
+            const size_t rows = std::min(chunk, batch - c0);
+            const char* src = (const char*)in + c0 * n * esz;
+            int cur = 1;  // the first pass writes bufs[0]
+            for (size_t pi = 0; pi < 2 * P; ++pi) {
+                const bool last1 = (pi == P - 1), last2 = (pi == 2 * P - 1);
+                char* dst = last2 ? (char*)out + c0 * n * esz : last1 ? (char*)src : bufs[1 - cur];
+                int rc = launch_pass<T>(plan, pi, src, dst, rows, stream, c0 == 0 ? tr : nullptr);
+                if (rc) return rc;
+                if (!last1 && !last2) cur = 1 - cur;
+                src = dst;
+            }
+        }
         return MI355FFT_OK;
     }
     if (plan.kind == PLAN_BLUESTEIN_LARGE) {

@@ -12,7 +12,7 @@
 
 namespace mi355 {
 
-enum PlanKind { PLAN_TRIVIAL = 0, PLAN_SINGLE = 1, PLAN_MACRO = 2, PLAN_BLUESTEIN = 3, PLAN_RADER = 4, PLAN_BLUESTEIN_LARGE = 5 };
+enum PlanKind { PLAN_TRIVIAL = 0, PLAN_SINGLE = 1, PLAN_MACRO = 2, PLAN_BLUESTEIN = 3, PLAN_RADER = 4, PLAN_BLUESTEIN_LARGE = 5, PLAN_BLUESTEIN_FUSED = 6 };
 
 struct PassDesc {
     const KernelEntry* k;
@@ -26,6 +26,7 @@ struct PassDesc {
     void* d_perm_in;   // Rader: g^(j+1) mod p
     void* d_perm_out;  // Rader: g^-(j+1) mod p
     DynSched dyn;      // run-time schedule (KIND_DYN_K1 / KIND_DYN_RADER)
+    long long row_n;   // transform length this pass belongs to when it is not the plan's own (fused Bluestein: M); 0 = plan.len
 };
 
 struct Workspace {
