@@ -183,7 +183,27 @@ def test_lengths_beyond_one_workgroup(emu_planner, oracle, dtype):
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
             assert ("k2gfirst" if n == 5000 else "bluestein_large") in fft.describe()
+            assert n == 5000 or " fused: k2gfirst_chirp" in fft.describe()  # element-wise stages ride on the passes
             check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=2)
+    # three passes per inner transform (M = 640000), ragged batch
+    fft = planner.plan_fft(300007, 0)
+    assert fft.describe().count("->") == 4, fft.describe()
+    x = zero_mean_signal(300007 * 2, dtype)
+    y = x.copy()
+    fft.process(y)
+    assert rel_l2(y, numpy_fft(x, 300007, False)) < (2e-6 if dtype == np.complex64 else 1e-13)
+    # the unfused fallback (separate chirp / multiply kernels around an inner plan) stays covered
+    import os
+
+    os.environ["MI355FFT_BLUESTEIN_UNFUSED"] = "1"
+    try:
+        fresh = emu_planner(dtype)
+        for n in (4097, 10007):
+            fft = fresh.plan_fft(n, 1)
+            assert "bluestein_large" in fft.describe() and "fused" not in fft.describe()
+            check_fft_algorithm(fft, n, 1, reference=oracle.plan(dtype, n, 1), n=2)
+    finally:
+        del os.environ["MI355FFT_BLUESTEIN_UNFUSED"]
 
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
