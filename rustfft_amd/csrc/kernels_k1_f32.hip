@@ -4,6 +4,14 @@
 namespace mi355 {
 void register_k1_f32(std::vector<KernelEntry>& reg) {
     MI_K1_LIST(float, 32);
+    // 2^13 .. 2^15 in ONE kernel: the real and imaginary planes go through LDS one after the other (split exchange), so a
+    // whole 32768-point row fits 132 KB.  Measured on MI355X: 18.0 / 20.8 / 20.3 TFLOP/s (4.6 / 4.8 / 4.3 TB/s) against
+    // 10.6 / 12.2 / 12.7 for two column-tile passes.  Variants: the 16-values-per-thread schedules (4.4 - 4.5 TB/s at 8192).
+    MI_K1(float, 32, 1, true, 8192, 256, 8, 32, 32);
+    MI_K1(float, 32, 1, true, 16384, 512, 16, 32, 32);
+    MI_K1(float, 32, 1, true, 32768, 1024, 32, 32, 32);
+    MI_K1V(3, float, 32, 1, false, 8192, 512, 16, 8, 8, 8);
+    MI_K1V(4, float, 32, 1, true, 8192, 512, 16, 8, 8, 8);
     // ablation probes of the 1024-point kernel (MI355FFT_VARIANT=5..7, wrong results by design): measured 5.36 TB/s for the
     // load/store skeleton against 5.1 - 5.2 TB/s for the full kernel.  Tuning history (no gain, removed): F = 2 / 8 rows per
     // workgroup, radix-8 schedules, 128-thread 4096 kernel, non-temporal loads/stores (tools/membench shows +11 % for an

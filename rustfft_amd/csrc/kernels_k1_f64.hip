@@ -4,5 +4,9 @@
 namespace mi355 {
 void register_k1_f64(std::vector<KernelEntry>& reg) {
     MI_K1_LIST(double, 64);
+    // 2^13, 2^14 in one kernel (split exchange): 10.0 / 10.1 TFLOP/s (5.05 / 4.7 TB/s) against 5.8 / 6.1 for two passes
+    MI_K1(double, 64, 1, true, 8192, 512, 16, 8, 8, 8);
+    MI_K1(double, 64, 1, true, 16384, 512, 16, 32, 32);
+    MI_K1V(3, double, 64, 1, true, 16384, 1024, 16, 16, 8, 8);
 }
 }  // namespace mi355

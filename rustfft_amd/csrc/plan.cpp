@@ -66,6 +66,14 @@ void ensure_registry() {
         register_smooth_f64_5(r);
         register_smooth_f64_6(r);
         register_smooth_f64_7(r);
+        register_smooth2_f32_0(r);
+        register_smooth2_f32_1(r);
+        register_smooth2_f32_2(r);
+        register_smooth2_f32_3(r);
+        register_smooth2_f64_0(r);
+        register_smooth2_f64_1(r);
+        register_smooth2_f64_2(r);
+        register_smooth2_f64_3(r);
     });
 }
 

@@ -73,6 +73,16 @@ void register_smooth_f64_5(std::vector<KernelEntry>&);
 void register_smooth_f64_6(std::vector<KernelEntry>&);
 void register_smooth_f64_7(std::vector<KernelEntry>&);
 
+// generated: single-kernel schedules for the 7-smooth lengths in (4096, 16384] (tools/gen_smooth_kernels.py main_big)
+void register_smooth2_f32_0(std::vector<KernelEntry>&);
+void register_smooth2_f32_1(std::vector<KernelEntry>&);
+void register_smooth2_f32_2(std::vector<KernelEntry>&);
+void register_smooth2_f32_3(std::vector<KernelEntry>&);
+void register_smooth2_f64_0(std::vector<KernelEntry>&);
+void register_smooth2_f64_1(std::vector<KernelEntry>&);
+void register_smooth2_f64_2(std::vector<KernelEntry>&);
+void register_smooth2_f64_3(std::vector<KernelEntry>&);
+
 template <class S> inline void fill_sched(KernelEntry& e) {
     e.tpf = S::TPF;
     e.np = S::NP;

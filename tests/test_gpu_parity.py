@@ -3,6 +3,7 @@ rustfft_amd host mirror, against the oracle (oracle/rustfft_scalar.hpp, RustFFT'
 seeded inputs.  Tolerance = the reference's own (tests/accuracy.rs:30-37): mean |a - b| < 0.1 on inputs
 re, im ~ U[0,10); in addition a relative-L2 bound vs a float64 reference is asserted (SURVEY App. C:
 O(eps log2 N): 5e-6 for f32, 1e-13 for f64)."""
+import os
 import threading
 
 import numpy as np
@@ -138,7 +139,7 @@ def test_full_size_properties_2p22(planners):
 def test_chunked_workspace_identical(planners):
     import torch
 
-    n, batch = 1 << 14, 37
+    n, batch = 1 << 17, 37
     fft = planners[np.dtype(np.complex64)].plan_fft_forward(n)
     x = torch.from_numpy(random_signal(n * batch, np.complex64)).cuda()
     a = x.clone()
@@ -304,7 +305,7 @@ def test_general_column_tile_passes(planners, oracle, dtype):
     do not divide the strides, ragged last tiles, powers of 3 and 5, ragged batches; vs the oracle's planner choice
     (RadixN / MixedRadix, src/plan.rs:430-560) up to 10^5, vs numpy complex128 beyond."""
     planner = planners[np.dtype(dtype)]
-    for n in (5000, 5488, 6000, 8000, 10000, 12000, 14000, 19683, 44100, 78125, 98304, 100000, 117649, 13122, 150000, 1000000, 1536000, 3 << 20, 5 << 21, 7 << 20):
+    for n in (17496, 19683, 25000, 44100, 78125, 98304, 100000, 117649, 150000, 1000000, 1536000, 3 << 20, 5 << 21, 7 << 20):
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
             assert fft.describe().startswith("k2gfirst"), (n, fft.describe())
@@ -326,6 +327,34 @@ def test_general_column_tile_passes(planners, oracle, dtype):
     assert abs((y.abs().pow(2).sum() / x.abs().pow(2).sum()).item() / n - 1) < 1e-4  # Parseval
     planner.plan_fft_inverse(n).process(y)
     assert ((y / n - x).abs().mean().item()) < (1e-5 if dtype == np.complex64 else 1e-13)
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_single_kernel_above_4096(planners, oracle, dtype):
+    """2^13 .. 2^15 (f32; 2^14 in f64) and every generated 7-smooth length in (4096, 16384] run as one split-exchange kernel:
+    vs the oracle's plan (Radix4 / RadixN, src/plan.rs:508-607) under the reference tolerance and vs numpy in float64."""
+    import glob
+    import re
+
+    planner = planners[np.dtype(dtype)]
+    tag = "f32" if dtype == np.complex64 else "f64"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sizes = [8192, 16384] + ([32768] if dtype == np.complex64 else [])
+    for f in glob.glob(os.path.join(root, "rustfft_amd", "csrc", "kernels_smooth2_%s_*.hip" % tag)):
+        sizes += [int(m) for m in re.findall(r"MI_K1\(\w+, \d+, 1, true, (\d+),", open(f).read())]
+    assert len(sizes) > 100
+    for n in sorted(sizes):
+        d = n % 2
+        fft = planner.plan_fft(n, d)
+        assert fft.describe().startswith("k1<%d," % n), (n, fft.describe())
+        x = random_signal(n * 3, dtype, seed=n)
+        y = x.copy()
+        fft.process(y)
+        if n % 7 == 0 or n in (8192, 16384, 32768, 10000):  # the oracle is the slow side: a subset against it, all against numpy
+            want = x.copy()
+            oracle.plan(dtype, n, d).process(want)
+            assert compare_vectors(want, y), n
+        assert rel_l2(y, numpy_fft(x, n, d == 1)) < REL[np.dtype(dtype)], n
 
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])

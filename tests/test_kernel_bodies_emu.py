@@ -25,7 +25,7 @@ def emu_planner():
 
 
 POW2_SINGLE = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096]
-POW2_MULTI = [1 << 13, 1 << 14, 1 << 15, 1 << 16, 1 << 17, 1 << 18]
+POW2_MULTI = [1 << 16, 1 << 17, 1 << 18, 1 << 19]  # 2^13 .. 2^15 are single split-exchange kernels (test_single_kernel_above_4096)
 
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
@@ -177,12 +177,12 @@ def test_baseline_configs_3_and_4(emu_planner, oracle, dtype):
 def test_lengths_beyond_one_workgroup(emu_planner, oracle, dtype):
     """Non-powers of two above 4096: a prime the reference plans as Rader (10007), a 'difficult' prime it plans as
     Bluestein (5759), a product of two large primes (101 * 103 -> MixedRadix) -- all multi-kernel Bluestein over the
-    large-N passes here -- and a smooth composite (5000 -> RadixN there, two general column-tile passes here)."""
+    large-N passes here -- and a smooth composite (5000 -> RadixN there, one split-exchange kernel here)."""
     planner = emu_planner(dtype)
     for n in (4097, 5000, 5759, 10007, 101 * 103):
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
-            assert ("k2gfirst" if n == 5000 else "bluestein_large") in fft.describe()
+            assert ("k1<5000" if n == 5000 else "bluestein_large") in fft.describe()
             assert n == 5000 or " fused: k2gfirst_chirp" in fft.describe()  # element-wise stages ride on the passes
             check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=2)
     # three passes per inner transform (M = 640000), ragged batch
@@ -212,12 +212,25 @@ def test_general_column_tile_passes(emu_planner, oracle, dtype):
     the strides (per-column b mod s), ragged last tiles (M not a multiple of F), pure powers of 3 and 5.  The
     reference plans these as RadixN / MixedRadix (src/plan.rs:430-560)."""
     planner = emu_planner(dtype)
-    for n, npass in ((5000, 2), (5488, 2), (6000, 2), (10000, 2), (19683, 2), (44100, 2), (78125, 2), (98304, 2), (100000, 2), (1000000, 3)):
+    for n, npass in ((17496, 2), (19683, 2), (25000, 2), (44100, 2), (78125, 2), (98304, 2), (100000, 2), (1000000, 3)):
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
             desc = fft.describe()
             assert desc.startswith("k2gfirst") and desc.count("->") == npass - 1, desc
             check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d) if n <= 100000 else None, n=2 if n <= 100000 else 1)
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_single_kernel_above_4096(emu_planner, oracle, dtype):
+    """2^13 .. 2^15 and the 7-smooth lengths up to 16384 run as ONE kernel whose LDS exchange moves the real and the imaginary
+    plane one after the other (engine.h SPLIT): all API modes vs the oracle's plan, every radix mix of the generated list."""
+    planner = emu_planner(dtype)
+    sizes = [4116, 4375, 5000, 6561, 8192, 10000, 12288, 16384] + ([14406, 15625, 16200, 32768] if dtype == np.complex64 else [])
+    for n in sizes:
+        for d in (0, 1):
+            fft = planner.plan_fft(n, d)
+            assert fft.describe().startswith("k1<%d," % n), (n, fft.describe())
+            check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=2)
 
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])

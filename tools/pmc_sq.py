@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Issue/stall breakdown of the bench's kernels from rocprofv3 SQ counters (two --pmc passes, 8 SQ slots each;
-MI355X_MICROARCH.md "rocprofv3 PMC slots").  Usage: python tools/pmc_sq.py [bench.py args...]
+MI355X_MICROARCH.md "rocprofv3 PMC slots").  Usage: python tools/pmc_sq.py [bench.py args...]  |  python tools/pmc_sq.py --sweep [tools/sweep.py args...]
 Prints one JSON object per kernel: counters averaged per dispatch + the derived fractions of SQ_WAVE_CYCLES."""
 import collections
 import csv
@@ -26,8 +26,11 @@ def main():
     res = collections.defaultdict(dict)
     for counters in PASSES:
         d = tempfile.mkdtemp(prefix="mi355sq_", dir="/tmp")
-        cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--",
-               sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-pmc"] + sys.argv[1:]
+        if len(sys.argv) > 1 and sys.argv[1] == "--sweep":  # python tools/pmc_sq.py --sweep --dtype f32 --sizes 1019
+            target = [sys.executable, os.path.join(ROOT, "tools", "sweep.py"), "--reps", "2"] + sys.argv[2:]
+        else:
+            target = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-pmc"] + sys.argv[1:]
+        cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--"] + target
         r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             print(r.stdout[-2000:], file=sys.stderr)
