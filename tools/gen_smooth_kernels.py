@@ -69,7 +69,50 @@ def rows_per_wg(n, tpf, esz):
     return f
 
 
+RADICES_BIG = [32, 30, 28, 27, 25, 24, 21, 20, 18, 16, 15, 14, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2]
+
+
+def factorizations_big(n, start=0):
+    if n == 1:
+        yield []
+        return
+    for i in range(start, len(RADICES_BIG)):
+        r = RADICES_BIG[i]
+        if n % r == 0:
+            for rest in factorizations_big(n // r, i):
+                yield [r] + rest
+
+
+def big_schedule32(n):
+    """f32, 32 values per thread, radices up to 32: fewest sub-passes (each one is an LDS round trip and two barriers)."""
+    best = None
+    for rad in factorizations_big(n):
+        if len(rad) > 4:
+            continue
+        tpf = max(math.ceil((n // r) / (32 // r)) for r in rad)
+        if tpf > 1024:
+            continue
+        util = sum((n // r) / (tpf * math.ceil((n // r) / tpf)) for r in rad) / len(rad)
+        waves = math.ceil(tpf / 64) * 64
+        util *= tpf / waves
+        key = (len(rad), -util)
+        if best is None or key < best[0]:
+            best = (key, sorted(rad, reverse=True), tpf)
+    return (best[1], best[2]) if best else None
+
+
+# f32 lengths for which the radix-32 rule measured > 20 % faster on MI355X than the 16-values-per-thread rule (A/B over all
+# 150 lengths, 1 GiB of rows each; the other 78 lengths are up to 37 % slower with it: odd thread counts, radices 25 - 30)
+BIG32_WINS = {4375, 4608, 4725, 5103, 5292, 5400, 5760, 5832, 6125, 6300, 7203, 7776, 7938, 8000, 8400, 8575, 9072, 9261, 9720,
+              10584, 11200, 11760, 11907, 12000, 12500, 12544, 12800, 13230, 13824, 14112, 14406, 15309, 15435, 15552,
+              15625, 16000}
+
+
 def big_schedule(n, emaxes=(16, 32)):
+    if 32 in emaxes and n in BIG32_WINS:
+        r = big_schedule32(n)
+        if r:
+            return r
     """(4096, 16384]: one workgroup per transform, up to 1024 threads; 16 values per thread, 32 where that needs more threads
     (f32 only: 32 double-precision values per thread spill)."""
     for emax in emaxes:
