@@ -52,6 +52,47 @@ MI_HD void k1_body(X& ex, const K1Params<T>& p, long long block, void* lds) {
     wg_fft<T, S, F, MAP_EF, MAP_EF, SPLIT, false, 1, (ABL & 15)>(ex, lds, p.tw, elem_src(src), dst);
 }
 
+// ---- two-kernel Bluestein for lengths whose padded size M still fits ONE workgroup through the split exchange ------
+// (4096 < n, 2n - 1 <= M <= 32768; bluesteins_algorithm.rs:100-136).  STAGE 1: rows of the caller (pitch n) times the
+// chirp, zero-padded on the fly -> FFT_M -> conj(X * bf) into the workspace (pitch M).  STAGE 2: workspace -> FFT_M ->
+// conj(X) * chirp, truncated to n, into the caller's rows.  Traffic 2 M + 2 n elements per transform.
+template <class T, class S, int F, bool SPLIT, int STAGE, class X>
+MI_HD void k1bs_body(X& ex, const BluesteinParams<T>& p, long long block, void* lds) {
+    constexpr unsigned M = S::N;
+    const long long fft0 = block * F;
+    const unsigned n = (unsigned)p.n;
+    const cx<T>* MI_RESTRICT in = p.in + fft0 * (STAGE == 1 ? (long long)n : (long long)M);
+    cx<T>* MI_RESTRICT out = p.out + fft0 * (STAGE == 1 ? (long long)M : (long long)n);
+    const cx<T>* MI_RESTRICT chirp = p.chirp;
+    const cx<T>* MI_RESTRICT bf = p.bf;
+    const int rows = (int)((p.batch - fft0) < F ? (p.batch - fft0) : F);
+    const T sgn = p.sgn;
+    auto src = [=](int f, int i) -> cx<T> {
+        if constexpr (STAGE == 1) {
+            if (f < rows && (unsigned)i < n) {
+                cx<T> x = in[(unsigned)f * n + (unsigned)i];
+                x.im *= sgn;
+                return x * chirp[(unsigned)i];
+            }
+            return cx<T>{0, 0};
+        } else {
+            return f < rows ? in[(unsigned)f * M + (unsigned)i] : cx<T>{0, 0};
+        }
+    };
+    auto dst = [=](int f, int j, cx<T> v) {
+        if (f < rows) {
+            if constexpr (STAGE == 1) {
+                out[(unsigned)f * M + (unsigned)j] = cconj(v * bf[(unsigned)j]);
+            } else if ((unsigned)j < n) {
+                cx<T> y = cconj(v) * chirp[(unsigned)j];
+                y.im *= sgn;
+                out[(unsigned)f * n + (unsigned)j] = y;
+            }
+        }
+    };
+    wg_fft<T, S, F, MAP_EF, MAP_EF, SPLIT>(ex, lds, p.tw, elem_src(src), dst);
+}
+
 // LDS pitch residue for a tile of F columns: lanes walk across the columns first, so the (32 / F) row slots of one
 // 32-lane group must fall on the banks the columns leave free
 constexpr int k2_pitch_mod(int f) { return f < 32 ? 32 / f : 1; }

@@ -11,6 +11,11 @@ void register_k1_f32(std::vector<KernelEntry>& reg) {
     MI_K1(float, 32, 1, true, 16384, 512, 16, 32, 32);
     MI_K1(float, 32, 1, true, 32768, 1024, 32, 32, 32);
     MI_K1V(3, float, 32, 1, false, 8192, 512, 16, 8, 8, 8);
+    // two-kernel Bluestein for 4096 < n <= 16384 (padded lengths 3 * 2^12, 2^14, 3 * 2^13, 2^15)
+    MI_BS2(float, 32, 1, true, 12288, 512, 32, 24, 16);
+    MI_BS2(float, 32, 1, true, 16384, 512, 16, 32, 32);
+    MI_BS2(float, 32, 1, true, 24576, 1024, 32, 32, 24);
+    MI_BS2(float, 32, 1, true, 32768, 1024, 32, 32, 32);
     MI_K1V(4, float, 32, 1, true, 8192, 512, 16, 8, 8, 8);
     // ablation probes of the 1024-point kernel (MI355FFT_VARIANT=5..7, wrong results by design): measured 5.36 TB/s for the
     // load/store skeleton against 5.1 - 5.2 TB/s for the full kernel.  Tuning history (no gain, removed): F = 2 / 8 rows per

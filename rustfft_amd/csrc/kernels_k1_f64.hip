@@ -8,5 +8,8 @@ void register_k1_f64(std::vector<KernelEntry>& reg) {
     MI_K1(double, 64, 1, true, 8192, 512, 16, 8, 8, 8);
     MI_K1(double, 64, 1, true, 16384, 512, 16, 32, 32);
     MI_K1V(3, double, 64, 1, true, 16384, 1024, 16, 16, 8, 8);
+    // two-kernel Bluestein for 4096 < n <= 8192
+    MI_BS2(double, 64, 1, true, 12288, 768, 16, 16, 16, 3);
+    MI_BS2(double, 64, 1, true, 16384, 512, 16, 32, 32);
 }
 }  // namespace mi355

@@ -43,6 +43,34 @@ __global__ __launch_bounds__(F* S::TPF, (F * S::TPF >= 512 ? 4 : 2)) void k2_ker
     k2_body<T, S, F, FIRST, SPLIT, ABL>(ex, p, (long long)blockIdx.x, smem);
 }
 
+template <class T, class S, int F, bool SPLIT, int STAGE>
+__global__ __launch_bounds__(F* S::TPF) void k1bs_kernel(BluesteinParams<T> p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevExec<T, regs_needed<S, SPLIT>()> ex;
+    k1bs_body<T, S, F, SPLIT, STAGE>(ex, p, (long long)blockIdx.x, smem);
+}
+template <class T, class S, int F, bool SPLIT, int STAGE> KernelEntry make_k1bs(int prec, const char* name) {
+    KernelEntry e{};
+    e.kind = STAGE == 1 ? KIND_BS2_FIRST : KIND_BS2_SECOND;
+    e.prec = prec;
+    e.n = S::N;
+    e.f = F;
+    fill_sched<S>(e);
+    e.threads = F * S::TPF;
+    e.lds_bytes = lds_bytes<T, S, F, SPLIT>();
+    e.split = SPLIT;
+    e.name = name;
+    e.launch = [](const void* params, long long grid, void* stream) {
+        void* args[] = {const_cast<void*>(params)};
+        (void)hipLaunchKernel((const void*)k1bs_kernel<T, S, F, SPLIT, STAGE>, dim3((unsigned)grid), dim3(F * S::TPF), args,
+                              lds_bytes<T, S, F, SPLIT>(), (hipStream_t)stream);
+    };
+    e.prepare = []() -> int {
+        return (int)hipFuncSetAttribute((const void*)k1bs_kernel<T, S, F, SPLIT, STAGE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds_bytes<T, S, F, SPLIT>());
+    };
+    return e;
+}
 template <class T, class S, int F, bool SPLIT, int ABL = 0> KernelEntry make_k1(int prec, const char* name) {
     KernelEntry e{};
     e.kind = KIND_K1;
@@ -260,6 +288,27 @@ template <class T, int NREG> struct HostExec {
     void barrier() {}
     void relaunder() {}
 };
+template <class T, class S, int F, bool SPLIT, int STAGE> KernelEntry make_k1bs(int prec, const char* name) {
+    KernelEntry e{};
+    e.kind = STAGE == 1 ? KIND_BS2_FIRST : KIND_BS2_SECOND;
+    e.prec = prec;
+    e.n = S::N;
+    e.f = F;
+    fill_sched<S>(e);
+    e.threads = F * S::TPF;
+    e.lds_bytes = lds_bytes<T, S, F, SPLIT>();
+    e.split = SPLIT;
+    e.name = name;
+    e.launch = [](const void* params, long long grid, void*) {
+        std::vector<char> lds(lds_bytes<T, S, F, SPLIT>() + 64, (char)0x5a);
+        for (long long b = 0; b < grid; ++b) {
+            HostExec<T, regs_needed<S, SPLIT>()> ex(F * S::TPF);
+            k1bs_body<T, S, F, SPLIT, STAGE>(ex, *(const BluesteinParams<T>*)params, b, lds.data());
+        }
+    };
+    e.prepare = []() -> int { return 0; };
+    return e;
+}
 template <class T, class S, int F, bool SPLIT, int ABL = 0> KernelEntry make_k1(int prec, const char* name) {
     KernelEntry e{};
     e.kind = KIND_K1;
@@ -450,6 +499,10 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
 #define MI_K2G(T, PREC, F, ...)                                                                        \
     reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, true>(PREC, "k2gfirst<" #__VA_ARGS__ ">xF" #F));  \
     reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, false>(PREC, "k2glater<" #__VA_ARGS__ ">xF" #F))
+// the two kernels of the two-kernel Bluestein for one padded length
+#define MI_BS2(T, PREC, F, SPLIT, ...)                                                                          \
+    reg.push_back(make_k1bs<T, Sched<__VA_ARGS__>, F, SPLIT, 1>(PREC, "bluestein2_first<" #__VA_ARGS__ ">xF" #F)); \
+    reg.push_back(make_k1bs<T, Sched<__VA_ARGS__>, F, SPLIT, 2>(PREC, "bluestein2_second<" #__VA_ARGS__ ">xF" #F))
 // the three fused passes of the multi-kernel Bluestein for one tile height
 #define MI_K2GF(T, PREC, F, ...)                                                                              \
     reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, true, 1>(PREC, "k2gfirst_chirp<" #__VA_ARGS__ ">xF" #F)); \

@@ -721,6 +721,41 @@ template <class T> static int build_plan_t(Plan& plan) {
             return MI355FFT_OK;
         }
     }
+    // 4096 < n with 2n - 1 <= 32768 (f64: 16384): two-kernel Bluestein, each kernel one whole-row transform of the padded
+    // length through the split exchange (k1bs_body)
+    if (env_int("MI355FFT_BLUESTEIN_UNFUSED") == 0) {
+        const KernelEntry* best = nullptr;
+        for (auto& e : registry())
+            if (e.kind == KIND_BS2_FIRST && e.prec == plan.prec && e.variant == 0 && (size_t)e.n >= 2 * n - 1 && (!best || e.n < best->n) &&
+                find_kernel(KIND_BS2_SECOND, plan.prec, e.n))
+                best = &e;
+        if (best) {
+            const KernelEntry* second = find_kernel(KIND_BS2_SECOND, plan.prec, best->n);
+            if (best->prepare() || second->prepare()) return MI355FFT_ERR_HIP;
+            const size_t M = best->n;
+            std::vector<cd> chirp = bluestein_chirp(n), bvec(M, cd(0, 0));
+            bvec[0] = std::conj(chirp[0]) / (double)M;
+            for (size_t i = 1; i < n; ++i) {
+                bvec[i] = std::conj(chirp[i]) / (double)M;
+                bvec[M - i] = bvec[i];
+            }
+            host_dft(bvec);
+            PassDesc pd{};
+            pd.k = best;
+            pd.row_n = (long long)M;
+            pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(*best), &rc);
+            if (rc) return rc;
+            pd.d_aux1 = upload<T>(plan, to_interleaved<T>(chirp), &rc);
+            if (rc) return rc;
+            pd.d_aux2 = upload<T>(plan, to_interleaved<T>(bvec), &rc);
+            if (rc) return rc;
+            plan.passes.push_back(pd);
+            pd.k = second;
+            plan.passes.push_back(pd);
+            plan.kind = PLAN_BLUESTEIN_2K;
+            return MI355FFT_OK;
+        }
+    }
     // any other length: multi-kernel Bluestein (bluesteins_algorithm.rs:58-136) with the inner FFT_M realised by the
     // general column-tile passes and the three element-wise stages fused into their first load / last store
     if (env_int("MI355FFT_BLUESTEIN_UNFUSED") == 0 && 2 * n - 1 < ((size_t)1 << 31) && choose_fused_radices(plan.prec, 2 * n - 1, radices)) {
@@ -888,7 +923,7 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         p.s = pd.dyn;
         grid = (long long)((batch + pd.dyn.f - 1) / pd.dyn.f);
         k.launch(&p, grid, stream);
-    } else if (k.kind == KIND_BLUESTEIN) {
+    } else if (k.kind == KIND_BLUESTEIN || k.kind == KIND_BS2_FIRST || k.kind == KIND_BS2_SECOND) {
         BluesteinParams<T> p{};
         p.in = (const cx<T>*)in;
         p.out = (cx<T>*)out;
@@ -954,6 +989,21 @@ template <class T> static int execute_t(Plan& plan, const void* in, void* out, s
     if (batch == 0 || n == 0) return MI355FFT_OK;
     if (plan.kind == PLAN_TRIVIAL) {  // len 1: the DFT is the identity (reference plans Dft(1), src/plan.rs:313-314)
         if (in != out && backend::d2d(out, in, batch * n * esz, stream)) return MI355FFT_ERR_HIP;
+        return MI355FFT_OK;
+    }
+    if (plan.kind == PLAN_BLUESTEIN_2K) {
+        const size_t M = (size_t)plan.passes[0].row_n;
+        size_t chunk = std::max<size_t>(1, ((size_t)1 << 32) / (M * esz));  // <= 4 GiB of padded rows at a time
+        if (chunk > batch) chunk = batch;
+        char* ws = (char*)plan.workspace_for(stream, chunk * M * esz);
+        if (!ws) return MI355FFT_ERR_OUT_OF_MEMORY;
+        for (size_t c0 = 0; c0 < batch; c0 += chunk) {
+            const size_t rows = std::min(chunk, batch - c0);
+            int rc = launch_pass<T>(plan, 0, (const char*)in + c0 * n * esz, ws, rows, stream, c0 == 0 ? tr : nullptr);
+            if (rc) return rc;
+            rc = launch_pass<T>(plan, 1, ws, (char*)out + c0 * n * esz, rows, stream, c0 == 0 ? tr : nullptr);
+            if (rc) return rc;
+        }
         return MI355FFT_OK;
     }
     if (plan.kind == PLAN_BLUESTEIN_FUSED) {

@@ -12,7 +12,7 @@
 
 namespace mi355 {
 
-enum PlanKind { PLAN_TRIVIAL = 0, PLAN_SINGLE = 1, PLAN_MACRO = 2, PLAN_BLUESTEIN = 3, PLAN_RADER = 4, PLAN_BLUESTEIN_LARGE = 5, PLAN_BLUESTEIN_FUSED = 6 };
+enum PlanKind { PLAN_TRIVIAL = 0, PLAN_SINGLE = 1, PLAN_MACRO = 2, PLAN_BLUESTEIN = 3, PLAN_RADER = 4, PLAN_BLUESTEIN_LARGE = 5, PLAN_BLUESTEIN_FUSED = 6, PLAN_BLUESTEIN_2K = 7 };
 
 struct PassDesc {
     const KernelEntry* k;

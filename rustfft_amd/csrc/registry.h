@@ -9,7 +9,9 @@ namespace mi355 {
 
 enum KernelKind { KIND_K1 = 1, KIND_K2_FIRST = 2, KIND_K2_LATER = 3, KIND_RADER = 4, KIND_BLUESTEIN = 5, KIND_POINTWISE = 6, KIND_DYN_K1 = 7, KIND_DYN_RADER = 8, KIND_K2G_FIRST = 9, KIND_K2G_LATER = 10,
                   // fused multi-kernel Bluestein passes (k2g_body FUSE = 1, 2, 3)
-                  KIND_K2G_FIRST_CHIRP = 11, KIND_K2G_LAST_MUL = 12, KIND_K2G_LAST_CHIRP = 13 };
+                  KIND_K2G_FIRST_CHIRP = 11, KIND_K2G_LAST_MUL = 12, KIND_K2G_LAST_CHIRP = 13,
+                  // two-kernel Bluestein over one-workgroup transforms (k1bs_body STAGE 1 / 2)
+                  KIND_BS2_FIRST = 14, KIND_BS2_SECOND = 15 };
 
 struct KernelEntry {
     int kind;

@@ -399,7 +399,7 @@ def test_random_lengths_vs_float64(planners, dtype):
         y = x.copy()
         fft.process(y)
         assert rel_l2(y, numpy_fft(x, n, d == 1)) < REL[np.dtype(dtype)], (n, batch, d, fft.describe())
-    assert {"k1", "k2first", "k2gfirst", "dyn_k1", "rader", "bluestein", "bluestein_large"} <= seen, seen
+    assert {"k1", "k2first", "k2gfirst", "dyn_k1", "rader", "bluestein", "bluestein2_first", "bluestein_large"} <= seen, seen
 
 
 def _thirteen_smooth(limit):

@@ -176,14 +176,20 @@ def test_baseline_configs_3_and_4(emu_planner, oracle, dtype):
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_lengths_beyond_one_workgroup(emu_planner, oracle, dtype):
     """Non-powers of two above 4096: a prime the reference plans as Rader (10007), a 'difficult' prime it plans as
-    Bluestein (5759), a product of two large primes (101 * 103 -> MixedRadix) -- all multi-kernel Bluestein over the
-    large-N passes here -- and a smooth composite (5000 -> RadixN there, one split-exchange kernel here)."""
+    Bluestein (5759), a product of two large primes (101 * 103 -> MixedRadix): two-kernel Bluestein here while the padded
+    length fits one workgroup, the fused multi-kernel Bluestein beyond (16411, 20011); and a smooth composite
+    (5000 -> RadixN there, one split-exchange kernel here)."""
     planner = emu_planner(dtype)
-    for n in (4097, 5000, 5759, 10007, 101 * 103):
+    two_kernel_limit = 16384 if dtype == np.complex64 else 8192  # padded length <= 32768 (f32) / 16384 (f64) fits one workgroup
+    for n in (4097, 5000, 5759, 10007, 101 * 103, 16411, 20011):
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
-            assert ("k1<5000" if n == 5000 else "bluestein_large") in fft.describe()
-            assert n == 5000 or " fused: k2gfirst_chirp" in fft.describe()  # element-wise stages ride on the passes
+            if n == 5000:
+                assert "k1<5000" in fft.describe()
+            elif n <= two_kernel_limit:
+                assert fft.describe().startswith("bluestein2_first<") and "bluestein2_second<" in fft.describe(), fft.describe()
+            else:
+                assert "bluestein_large" in fft.describe() and " fused: k2gfirst_chirp" in fft.describe(), fft.describe()
             check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=2)
     # three passes per inner transform (M = 640000), ragged batch
     fft = planner.plan_fft(300007, 0)
