@@ -73,6 +73,46 @@ template <class V, int F, int R, int NT> __global__ __launch_bounds__(NT) void t
         for (int k = 0; k < E; ++k) dstc[threadIdx.x + k * NT] = v[k];
     }
 }
+// the 1024x16 tile with the FFT kernels' own access order: loads as sub-pass 0 issues them (radix 8, butterflies u + 32 m, rows
+// b + 128 k), stores as the last sub-pass issues them (radix 16, rows b + 64 k); ORD bit 0: FFT load order, bit 1: FFT store order
+template <int BARRIER, int ORD> __global__ __launch_bounds__(512, 4) void tile_fftorder(const float2* __restrict__ in, float2* __restrict__ out, size_t M, int strided_out) {
+    extern __shared__ char smem[];
+    const size_t tiles = M / 16;
+    const size_t g = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    const float2* src = in + g * M * 1024 + tile * 16;
+    float2* dsto = out + g * M * 1024 + tile * 16;
+    float2* dstc = out + ((size_t)blockIdx.x) * (16 * 1024);
+    const int f = threadIdx.x % 16, u = threadIdx.x / 16;
+    float2 v[32];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int row = (ORD & 1) ? (u + 32 * m + 128 * k) : (u + 32 * (m * 8 + k));
+            v[m * 8 + k] = src[f + (size_t)row * M];
+        }
+    if (threadIdx.x == 0 && M == 1) smem[0] = 1;
+    if (BARRIER) __syncthreads();
+    if (strided_out) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int row = (ORD & 2) ? (u + 32 * m + 64 * k) : (u + 32 * (m * 16 + k));
+                dsto[f + (size_t)row * M] = v[m * 16 + k];
+            }
+    } else {
+        const int uu = threadIdx.x % 32, ff = threadIdx.x / 32;  // lanes along the rows of one column, as MAP_EF stores
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int row = (ORD & 2) ? (uu + 32 * m + 64 * k) : (uu + 32 * (m * 16 + k));
+                dstc[ff * 1024 + row] = v[m * 16 + k];
+            }
+    }
+}
+
 template <class K> float time_it(K&& launch, int reps = 5) {
     hipEvent_t a, b;
     hipEventCreate(&a);
@@ -128,6 +168,16 @@ int main() {
         snprintf(nm, sizeof nm, "tile 256x32 512thr x16, LDS %d, wr-strided (M=4096)", lds);
         report(nm, time_it([&] { tilecopy_lds<float2, 32, 256, 512><<<batch * 128, 512, lds>>>((float2*)a, (float2*)b, 4096, 1); }));
     }
+#define FFTORD(B, O)                                                                                                          \
+    hipFuncSetAttribute((const void*)tile_fftorder<B, O>, hipFuncAttributeMaxDynamicSharedMemorySize, 150000);                   \
+    report("fft-order tile barrier=" #B " ord=" #O " wr-contig", time_it([&] { tile_fftorder<B, O><<<batch * 64, 512, 70000>>>((float2*)a, (float2*)b, 1024, 0); })); \
+    report("fft-order tile barrier=" #B " ord=" #O " wr-strided", time_it([&] { tile_fftorder<B, O><<<batch * 64, 512, 70000>>>((float2*)a, (float2*)b, 1024, 1); }));
+    FFTORD(1, 0)
+    FFTORD(0, 0)
+    FFTORD(0, 1)
+    FFTORD(0, 2)
+    FFTORD(0, 3)
+    FFTORD(1, 3)
     hipMemcpy(b, a, bytes, hipMemcpyDeviceToDevice);
     report("hipMemcpy D2D", time_it([&] { hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0); }));
     return 0;
