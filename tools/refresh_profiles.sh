@@ -28,5 +28,6 @@ python tools/sweep.py --dtype f64 --sizes $NP2 > $OUT/sweep_np2_f64.jsonl 2>/dev
 ( cd /tmp && python $ROOT/tools/pmc_sq.py --config c3 --steps 2 --warmup 1 > $OUT/sq_counters_c3.jsonl 2>/dev/null )
 ( cd /tmp && python $ROOT/tools/pmc_sq.py --config c4 --steps 2 --warmup 1 > $OUT/sq_counters_c4.jsonl 2>/dev/null )
 # 6. the copy ceiling of this box
+if [ ! -x tools/membench/membench ]; then hipcc --offload-arch=gfx950 -O3 tools/membench/membench.hip -o tools/membench/membench 2>/dev/null; fi
 if [ -x tools/membench/membench ]; then tools/membench/membench > $OUT/membench.txt 2>&1; fi
 ls -la $OUT
