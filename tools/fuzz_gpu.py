@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""One-off robustness sweep on the GPU: random lengths (log-uniform in [2, 3e6]) x random ragged batches x both precisions
+x both directions x the three API modes, against numpy.fft in complex128.  Prints one line per failure and a summary.
+Usage: python tools/fuzz_gpu.py [count] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rustfft_amd  # noqa: E402
+
+
+def main():
+    count = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    planners = {np.complex64: rustfft_amd.FftPlanner(np.complex64), np.complex128: rustfft_amd.FftPlanner(np.complex128)}
+    tol = {np.complex64: 5e-6, np.complex128: 1e-13}
+    kinds, bad = {}, 0
+    for it in range(count):
+        n = int(np.exp(rng.uniform(np.log(2), np.log(3e6))))
+        if it % 2 == 1:  # smooth lengths: products of small primes (the compiled schedules and the column-tile passes)
+            n = 1
+            while True:
+                p = int(rng.choice([2, 2, 2, 3, 3, 5, 5, 7, 11, 13]))
+                if n * p > 3_000_000 or (n > 16 and rng.uniform() < 0.12):
+                    break
+                n *= p
+            n = max(n, 2)
+        if it % 7 == 0:  # edge neighbourhoods of the planner's thresholds
+            n = int(rng.choice([4096, 4097, 8191, 8193, 16383, 16384, 16385, 32768, 32769, 2 * 16384 - 1, 409600, 409601])) + int(rng.integers(0, 2))
+        dt = np.complex64 if rng.integers(0, 2) else np.complex128
+        d = int(rng.integers(0, 2))
+        batch = int(rng.integers(1, max(2, min(50, 3_000_000 // n))))
+        mode = int(rng.integers(0, 3))
+        x = (rng.uniform(-1, 1, n * batch) + 1j * rng.uniform(-1, 1, n * batch)).astype(dt)
+        fft = planners[dt].plan_fft(n, d)
+        kinds[fft.describe().split("<")[0].split("(")[0]] = kinds.get(fft.describe().split("<")[0].split("(")[0], 0) + 1
+        if mode == 0:
+            y = x.copy()
+            fft.process(y)
+        elif mode == 1:
+            y = np.zeros_like(x)
+            xin = x.copy()
+            fft.process_outofplace_with_scratch(xin, y, np.zeros(fft.get_outofplace_scratch_len(), dtype=dt))
+        else:
+            y = np.zeros_like(x)
+            xin = x.copy()
+            fft.process_immutable_with_scratch(xin, y, np.zeros(fft.get_immutable_scratch_len(), dtype=dt))
+            assert np.array_equal(xin, x)
+        X = x.reshape(batch, n).astype(np.complex128)
+        ref = np.fft.fft(X, axis=1) if d == 0 else np.fft.ifft(X, axis=1) * n
+        err = np.linalg.norm(y.reshape(batch, n) - ref) / np.linalg.norm(ref)
+        if not (err < tol[dt]):
+            bad += 1
+            print("FAIL", n, dt.__name__, d, batch, mode, f"{err:.3e}", fft.describe(), flush=True)
+    print("done:", count, "cases,", bad, "failures; plan kinds:", kinds)
+
+
+if __name__ == "__main__":
+    main()
