@@ -126,6 +126,8 @@ Plan::~Plan() {
     backend::sync(nullptr);
     for (void* p : device_allocs) backend::dfree(p);
     for (auto& kv : workspaces) backend::dfree(kv.second.ptr);
+    backend::dfree(stage_a.ptr);  // host-slice staging buffers
+    backend::dfree(stage_b.ptr);
 }
 
 template <class T> static void* upload(Plan& plan, const std::vector<T>& host, int* rc) {
