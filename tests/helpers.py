@@ -88,3 +88,16 @@ def check_fft_algorithm(fft, length, direction, reference=None, n=3):
         fft.process_immutable_with_scratch(inp, out, scratch)
         assert compare_vectors(expected, out), f"process_immutable_with_scratch() failed, length = {length}"
         assert np.array_equal(inp, x), "immutable input was modified"
+
+
+def build_cpp_mirror_check():
+    """Compiles tests/cpp/mirror_check.cpp (the C++17 host mirror's own check program) against the in-tree library."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "mirror_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", os.path.join(root, "tests", "cpp", "mirror_check.cpp"), "-o", exe,
+                           "-L" + os.path.join(root, "rustfft_amd", "lib"), "-lmi355fft",
+                           "-Wl,-rpath," + os.path.join(root, "rustfft_amd", "lib")])
+    return exe

@@ -65,3 +65,20 @@ def test_strerror_covers_reference_panics(hiplib):
     assert "must be a multiple of FFT length" in msgs[3]
     assert "Not enough scratch space" in msgs[4]
     assert "must have the same length" in msgs[5]
+
+
+def test_cpp_host_mirror_fails_loudly_without_gpu(hiplib):
+    """rustfft_amd/host/mi355fft.hpp (FftPlanner<T> / Fft<T> in C++17 over the C ABI) compiles against include/mi355fft.h and,
+    with no gfx950 device, its planner constructor throws FftPanic(NO_DEVICE) -- no CPU fallback behind the mirror either."""
+    import subprocess
+
+    import torch
+
+    from helpers import build_cpp_mirror_check
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by the -m gpu run of the same program")
+    exe = build_cpp_mirror_check()
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)
+    assert "no gfx950" in r.stdout

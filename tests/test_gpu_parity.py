@@ -425,3 +425,17 @@ def test_compiled_smooth_schedules(planners, oracle, dtype):
         oracle.plan(dtype, n, d).process(want)
         assert compare_vectors(want, y), n
         assert rel_l2(y, numpy_fft(x, n, d == 1)) < REL[np.dtype(dtype)], n
+
+
+def test_cpp_host_mirror(planners):
+    """The C++17 mirror of FftPlanner / Fft (rustfft_amd/host/mi355fft.hpp): tests/cpp/mirror_check.cpp restates
+    check_fft_algorithm (src/test_utils.rs:70-209) in C++ over the C ABI -- four entry points, dirty scratch, planner cache,
+    panic text -- for ten lengths x two directions x two precisions against the O(n^2) definition."""
+    import subprocess
+
+    from helpers import build_cpp_mirror_check
+
+    exe = build_cpp_mirror_check()
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert r.stdout.count("ok n=") == 40
