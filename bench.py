@@ -59,9 +59,23 @@ def cpu_baseline(n, log):
     t = fwd.time_batch(buf, batch, 1, cores) + inv.time_batch(buf, batch, 1, cores)
     flops = 2 * batch * 5.0 * n * math.log2(n)
     log(f"cpu_baseline: {batch} transforms fwd+inv on {cores} threads in {t:.2f}s")
-    return {"value": flops / t / 1e9, "unit": "GFLOP/s", "cores": cores, "kind": "port",
-            "sample": f"N=2^{int(math.log2(n))} Complex<f32>, {batch} transforms forward+inverse, {cores} caller threads sharing one plan "
-                      f"(scalar-path restatement compiled -O2 -ffp-contract=off, not the RustFFT binary)"}
+    out = {"value": flops / t / 1e9, "unit": "GFLOP/s", "cores": cores, "kind": "port",
+           "sample": f"N=2^{int(math.log2(n))} Complex<f32>, {batch} transforms forward+inverse, {cores} caller threads sharing one plan "
+                     f"(scalar-path restatement compiled -O2 -ffp-contract=off, not the RustFFT binary)"}
+    try:  # external CPU yardstick asked for by SURVEY.md section 8(d): pocketfft (scipy.fft) on every core, same workload shape
+        import scipy.fft
+
+        yb = min(batch, 512)
+        ybuf = np.tile(one, yb).reshape(yb, n)
+        scipy.fft.fft(ybuf[:8], axis=1, workers=cores)
+        t0 = time.perf_counter()
+        scipy.fft.ifft(scipy.fft.fft(ybuf, axis=1, workers=cores), axis=1, workers=cores)
+        ty = time.perf_counter() - t0
+        out["yardstick"] = {"what": f"scipy.fft (pocketfft) complex64, {yb} transforms forward+inverse, workers={cores}",
+                            "value": 2 * yb * 5.0 * n * math.log2(n) / ty / 1e9, "unit": "GFLOP/s"}
+    except Exception as e:
+        log(f"scipy yardstick unavailable: {e}")
+    return out
 
 
 def side_config(args, rank, local_rank, world, dist, log):
