@@ -126,6 +126,16 @@ def side_config(args, rank, local_rank, world, dist, log):
             dom = max(timed, key=lambda r: r["ms"])
             out["roofline"] = {"bound": "hbm", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dom["GBps"] / HBM_PEAK_GBS,
                                "traffic": None, "kernel": dom["kernel"], "algorithmic_bytes_per_launch": alg, "kernels": per_kernel}
+            if world == 1 and not args.no_pmc:
+                try:
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                    import pmc_traffic
+
+                    for rk, rv in pmc_traffic.collect(["--config", args.config, "--steps", "1", "--warmup", "1"]).items():
+                        if pmc_traffic.rocprof_name_matches(dom["kernel"], rk):
+                            out["roofline"]["traffic"] = rv["traffic_bytes"]
+                except Exception as e:
+                    log(f"pmc traffic unavailable: {e}")
         print(json.dumps(out), flush=True)
     if dist:
         dist.destroy_process_group()

@@ -53,7 +53,11 @@ def rocprof_name_matches(entry_name, rocprof_name):
     """'k2later<1024, 32, 8, 8, 16>xF16' <-> 'void mi355::k2_kernel<float, mi355::Sched<1024, 32, 8, 8, 16>, 16, false, true>(...)'"""
     kind, rest = entry_name.split("<", 1)
     args, tail = rest.rsplit(">xF", 1)
-    f = "".join(ch for ch in tail if ch.isdigit() or ch == "v").split("v")[0]
+    f = ""
+    for ch in tail:  # leading digits = sequences / columns per workgroup; suffixes (v3, m2, abl13) follow
+        if not ch.isdigit():
+            break
+        f += ch
     if f"Sched<{args}>, {f}," not in rocprof_name:
         return False
     if kind == "k2first":
