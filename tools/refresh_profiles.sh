@@ -12,7 +12,7 @@ python bench.py > $OUT/bench_final.json 2> $OUT/bench_final.stderr
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_c2 -o c2 --output-format csv -- python $ROOT/bench.py --no-pmc --no-cpu-baseline > $OUT/bench_under_rocprof.json 2>/dev/null )
 cp $(find /tmp/prof_c2 -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv 2>/dev/null
 # 3. the other BASELINE configs
-for c in c3 c4 c5; do python bench.py --config $c --no-cpu-baseline > $OUT/bench_$c.json 2>/dev/null; done
+for c in c3 c4 c5; do python bench.py --config $c --no-cpu-baseline > $OUT/bench_$c.json 2>/dev/null; done  # roofline.traffic from PMC included
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_c4 -o c4 --output-format csv -- python $ROOT/bench.py --config c4 --no-pmc --no-cpu-baseline > /dev/null 2>&1 )
 cp $(find /tmp/prof_c4 -name "*kernel_stats.csv" | head -1) $OUT/bench_c4_kernel_stats.csv 2>/dev/null
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_c3 -o c3 --output-format csv -- python $ROOT/bench.py --config c3 --no-pmc --no-cpu-baseline > /dev/null 2>&1 )
