@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One-off robustness sweep on the GPU: random lengths (log-uniform in [2, 3e6]) x random ragged batches x both precisions
 x both directions x the three API modes, against numpy.fft in complex128.  Prints one line per failure and a summary.
-Usage: python tools/fuzz_gpu.py [count] [seed]"""
+Usage: python tools/fuzz_gpu.py [count] [seed] [device]   (third argument "device": HBM-resident torch tensors through the
+_dev entry points instead of host slices)"""
 import os
 import sys
 
@@ -14,6 +15,9 @@ import rustfft_amd  # noqa: E402
 def main():
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 400
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    on_device = len(sys.argv) > 3 and sys.argv[3] == "device"
+    if on_device:
+        import torch
     rng = np.random.default_rng(seed)
     planners = {np.complex64: rustfft_amd.FftPlanner(np.complex64), np.complex128: rustfft_amd.FftPlanner(np.complex128)}
     tol = {np.complex64: 5e-6, np.complex128: 1e-13}
@@ -37,7 +41,21 @@ def main():
         x = (rng.uniform(-1, 1, n * batch) + 1j * rng.uniform(-1, 1, n * batch)).astype(dt)
         fft = planners[dt].plan_fft(n, d)
         kinds[fft.describe().split("<")[0].split("(")[0]] = kinds.get(fft.describe().split("<")[0].split("(")[0], 0) + 1
-        if mode == 0:
+        if on_device:
+            tx = torch.from_numpy(x).cuda()
+            if mode == 0:
+                ty = tx.clone()
+                fft.process(ty)
+            elif mode == 1:
+                ty = torch.zeros_like(tx)
+                fft.process_outofplace_with_scratch(tx.clone(), ty)
+            else:
+                ty = torch.zeros_like(tx)
+                keep = tx.clone()
+                fft.process_immutable_with_scratch(tx, ty)
+                assert torch.equal(keep, tx)
+            y = ty.cpu().numpy()
+        elif mode == 0:
             y = x.copy()
             fft.process(y)
         elif mode == 1:
