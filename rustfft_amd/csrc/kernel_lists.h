@@ -29,7 +29,6 @@
     MI_BS(T, PREC, 32, 128, 8, 16, 8);             \
     MI_BS(T, PREC, 16, 256, 16, 16, 16);           \
     MI_BS(T, PREC, 8, 512, 32, 16, 8, 4);          \
-    MI_BS(T, PREC, 4, 1024, 64, 16, 16, 4);        \
     MI_BS(T, PREC, 2, 2048, 128, 16, 16, 8);       \
     MI_BS(T, PREC, 1, 4096, 256, 16, 16, 16)
 
