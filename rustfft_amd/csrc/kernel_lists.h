@@ -30,7 +30,6 @@
     MI_BS(T, PREC, 8, 64, 8, 8, 8);                \
     MI_BS(T, PREC, 8, 128, 8, 16, 8);              \
     MI_BS(T, PREC, 2, 256, 32, 8, 8, 4);           \
-    MI_BS(T, PREC, 2, 2048, 128, 16, 16, 8);       \
     MI_BS(T, PREC, 1, 4096, 256, 16, 16, 16)
 
 // Bluestein bodies over the 3 * 2^k inner lengths (the reference's second family, src/plan.rs:649-657): the planner takes
@@ -43,7 +42,7 @@
     MI_BS(T, PREC, 16, 192, 16, 16, 12);  \
     MI_BS(T, PREC, 1, 384, 64, 6, 8, 8);  \
     MI_BS(T, PREC, 1, 768, 96, 8, 8, 12);  \
-    MI_BS(T, PREC, 2, 1536, 128, 16, 16, 6);  \
+    MI_BS(T, PREC, 1, 1536, 128, 16, 16, 6);  \
     MI_BS(T, PREC, 1, 3072, 256, 16, 16, 12);  \
     MI_BS(T, PREC, 1, 6144, 512, 16, 16, 24)
 #define MI_BS_LIST3_F64(T, PREC)                  \

@@ -20,6 +20,7 @@ void register_np2_f32(std::vector<KernelEntry>& reg) {
     MI_BS_LIST(float, 32);
     MI_BS(float, 32, 2, 512, 64, 8, 8, 8);
     MI_BS(float, 32, 1, 1024, 64, 16, 16, 4);    // one wave per row: 1.68 TB/s against 1.55 with four rows per workgroup
+    MI_BS(float, 32, 1, 2048, 128, 16, 16, 8);
     MI_BS(float, 32, 1, 8192, 512, 16, 16, 32);  // 1.22 TB/s against 0.97 for 16 x 8 x 8 x 8 (one exchange fewer)
     MI_BS_LIST3_F32(float, 32);
     reg.push_back(make_pointwise<float>(32));

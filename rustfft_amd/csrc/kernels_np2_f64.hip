@@ -14,6 +14,7 @@ void register_np2_f64(std::vector<KernelEntry>& reg) {
     MI_BS_LIST(double, 64);
     MI_BS(double, 64, 1, 512, 64, 8, 8, 8);
     MI_BS(double, 64, 4, 1024, 64, 16, 16, 4);
+    MI_BS(double, 64, 2, 2048, 128, 16, 16, 8);
     MI_BS(double, 64, 1, 8192, 512, 16, 8, 8, 8);  // the radix-32 last pass spills in f64
     MI_BS_LIST3_F64(double, 64);
     reg.push_back(make_pointwise<double>(64));
