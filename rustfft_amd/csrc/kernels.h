@@ -249,7 +249,7 @@ template <class T, bool FIRST, int FUSE = 0> struct K2gSrc {
     }
 };
 
-template <class T, class S, int F, bool FIRST, int FUSE, class X>
+template <class T, class S, int F, bool FIRST, int FUSE, bool SPLIT = false, class X>
 MI_HD void k2g_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     static_assert(FUSE == 0 || (FUSE == 1) == FIRST, "chirp-in fuses into a first pass, the output stages into a last pass");
     constexpr int R = S::N;
@@ -285,7 +285,7 @@ MI_HD void k2g_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
             }
         }
     };
-    wg_fft<T, S, F, MAP_FF, FIRST ? MAP_EF : MAP_FF, false, false, k2_pitch_mod(F)>(ex, lds, p.tw, src, dst);
+    wg_fft<T, S, F, MAP_FF, FIRST ? MAP_EF : MAP_FF, SPLIT, false, k2_pitch_mod(F)>(ex, lds, p.tw, src, dst);
 }
 
 // ---- Bluestein: any length n <= (M + 1) / 2 through two length-M workgroup transforms ---------------------

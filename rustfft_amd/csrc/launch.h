@@ -199,13 +199,14 @@ template <class T, class S, int F, int MODE> KernelEntry make_rader(int prec, co
     };
     return e;
 }
-template <class T, class S, int F, bool FIRST, int FUSE>
-__global__ __launch_bounds__(F* S::TPF) void k2g_kernel(K2Params<T> p) {
+// SPLIT (tall tiles): two workgroups per CU, as for the power-of-two tiles
+template <class T, class S, int F, bool FIRST, int FUSE, bool SPLIT>
+__global__ __launch_bounds__(F* S::TPF, (SPLIT ? (F * S::TPF >= 512 ? 4 : 2) : 1)) void k2g_kernel(K2Params<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    DevExec<T, regs_needed<S, false>()> ex;
-    k2g_body<T, S, F, FIRST, FUSE>(ex, p, (long long)blockIdx.x, smem);
+    DevExec<T, regs_needed<S, SPLIT>()> ex;
+    k2g_body<T, S, F, FIRST, FUSE, SPLIT>(ex, p, (long long)blockIdx.x, smem);
 }
-template <class T, class S, int F, bool FIRST, int FUSE = 0> KernelEntry make_k2g(int prec, const char* name) {
+template <class T, class S, int F, bool FIRST, int FUSE = 0, bool SPLIT = false> KernelEntry make_k2g(int prec, const char* name) {
     KernelEntry e{};
     e.kind = FUSE == 1 ? KIND_K2G_FIRST_CHIRP : FUSE == 2 ? KIND_K2G_LAST_MUL : FUSE == 3 ? KIND_K2G_LAST_CHIRP : FIRST ? KIND_K2G_FIRST : KIND_K2G_LATER;
     e.prec = prec;
@@ -213,16 +214,17 @@ template <class T, class S, int F, bool FIRST, int FUSE = 0> KernelEntry make_k2
     e.f = F;
     fill_sched<S>(e);
     e.threads = F * S::TPF;
-    e.lds_bytes = lds_bytes<T, S, F, false, k2_pitch_mod(F)>();
+    e.lds_bytes = lds_bytes<T, S, F, SPLIT, k2_pitch_mod(F)>();
+    e.split = SPLIT;
     e.name = name;
     e.launch = [](const void* params, long long grid, void* stream) {
         void* args[] = {const_cast<void*>(params)};
-        (void)hipLaunchKernel((const void*)k2g_kernel<T, S, F, FIRST, FUSE>, dim3((unsigned)grid), dim3(F * S::TPF), args,
-                              lds_bytes<T, S, F, false, k2_pitch_mod(F)>(), (hipStream_t)stream);
+        (void)hipLaunchKernel((const void*)k2g_kernel<T, S, F, FIRST, FUSE, SPLIT>, dim3((unsigned)grid), dim3(F * S::TPF), args,
+                              lds_bytes<T, S, F, SPLIT, k2_pitch_mod(F)>(), (hipStream_t)stream);
     };
     e.prepare = []() -> int {
-        return (int)hipFuncSetAttribute((const void*)k2g_kernel<T, S, F, FIRST, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds_bytes<T, S, F, false, k2_pitch_mod(F)>());
+        return (int)hipFuncSetAttribute((const void*)k2g_kernel<T, S, F, FIRST, FUSE, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds_bytes<T, S, F, SPLIT, k2_pitch_mod(F)>());
     };
     return e;
 }
@@ -414,7 +416,7 @@ template <class T, class S, int F, int MODE> KernelEntry make_rader(int prec, co
     e.prepare = []() -> int { return 0; };
     return e;
 }
-template <class T, class S, int F, bool FIRST, int FUSE = 0> KernelEntry make_k2g(int prec, const char* name) {
+template <class T, class S, int F, bool FIRST, int FUSE = 0, bool SPLIT = false> KernelEntry make_k2g(int prec, const char* name) {
     KernelEntry e{};
     e.kind = FUSE == 1 ? KIND_K2G_FIRST_CHIRP : FUSE == 2 ? KIND_K2G_LAST_MUL : FUSE == 3 ? KIND_K2G_LAST_CHIRP : FIRST ? KIND_K2G_FIRST : KIND_K2G_LATER;
     e.prec = prec;
@@ -422,13 +424,14 @@ template <class T, class S, int F, bool FIRST, int FUSE = 0> KernelEntry make_k2
     e.f = F;
     fill_sched<S>(e);
     e.threads = F * S::TPF;
-    e.lds_bytes = lds_bytes<T, S, F, false, k2_pitch_mod(F)>();
+    e.lds_bytes = lds_bytes<T, S, F, SPLIT, k2_pitch_mod(F)>();
+    e.split = SPLIT;
     e.name = name;
     e.launch = [](const void* params, long long grid, void*) {
-        std::vector<char> lds(lds_bytes<T, S, F, false, k2_pitch_mod(F)>() + 64, (char)0x5a);
+        std::vector<char> lds(lds_bytes<T, S, F, SPLIT, k2_pitch_mod(F)>() + 64, (char)0x5a);
         for (long long b = 0; b < grid; ++b) {
-            HostExec<T, regs_needed<S, false>()> ex(F * S::TPF);
-            k2g_body<T, S, F, FIRST, FUSE>(ex, *(const K2Params<T>*)params, b, lds.data());
+            HostExec<T, regs_needed<S, SPLIT>()> ex(F * S::TPF);
+            k2g_body<T, S, F, FIRST, FUSE, SPLIT>(ex, *(const K2Params<T>*)params, b, lds.data());
         }
     };
     e.prepare = []() -> int { return 0; };
@@ -499,6 +502,10 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
 #define MI_K2G(T, PREC, F, ...)                                                                        \
     reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, true>(PREC, "k2gfirst<" #__VA_ARGS__ ">xF" #F));  \
     reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, false>(PREC, "k2glater<" #__VA_ARGS__ ">xF" #F))
+// tall general tiles (split exchange, 32 values per thread)
+#define MI_K2GS(T, PREC, F, ...)                                                                                      \
+    reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, true, 0, true>(PREC, "k2gfirst<" #__VA_ARGS__ ">xF" #F "s"));  \
+    reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, false, 0, true>(PREC, "k2glater<" #__VA_ARGS__ ">xF" #F "s"))
 // the two kernels of the two-kernel Bluestein for one padded length
 #define MI_BS2(T, PREC, F, SPLIT, ...)                                                                          \
     reg.push_back(make_k1bs<T, Sched<__VA_ARGS__>, F, SPLIT, 1>(PREC, "bluestein2_first<" #__VA_ARGS__ ">xF" #F)); \

@@ -218,11 +218,12 @@ def test_general_column_tile_passes(emu_planner, oracle, dtype):
     the strides (per-column b mod s), ragged last tiles (M not a multiple of F), pure powers of 3 and 5.  The
     reference plans these as RadixN / MixedRadix (src/plan.rs:430-560)."""
     planner = emu_planner(dtype)
-    for n, npass in ((17496, 2), (19683, 2), (25000, 2), (44100, 2), (78125, 2), (98304, 2), (100000, 2), (1000000, 3)):
+    for n, npass in ((17496, 2), (19683, 2), (25000, 2), (44100, 2), (78125, 2), (98304, 2), (100000, 2), (1000000, 3), (3686400, 3)):
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
             desc = fft.describe()
-            assert desc.startswith("k2gfirst") and desc.count("->") == npass - 1, desc
+            want = 2 if (n >= 1000000 and dtype == np.complex128) else npass  # f64 has the tall split tiles: 1000 x 1000
+            assert desc.startswith("k2gfirst") and desc.count("->") == want - 1, desc
             check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d) if n <= 100000 else None, n=2 if n <= 100000 else 1)
 
 
