@@ -218,7 +218,7 @@ def test_general_column_tile_passes(emu_planner, oracle, dtype):
     the strides (per-column b mod s), ragged last tiles (M not a multiple of F), pure powers of 3 and 5.  The
     reference plans these as RadixN / MixedRadix (src/plan.rs:430-560)."""
     planner = emu_planner(dtype)
-    for n, npass in ((17496, 2), (19683, 2), (25000, 2), (44100, 2), (78125, 2), (98304, 2), (100000, 2), (1000000, 3), (3686400, 3)):
+    for n, npass in ((36864, 2), (39366, 2), (50000, 2), (44100, 2), (78125, 2), (98304, 2), (100000, 2), (1000000, 3), (3686400, 3)):
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
             desc = fft.describe()
@@ -232,7 +232,7 @@ def test_single_kernel_above_4096(emu_planner, oracle, dtype):
     """2^13 .. 2^15 and the 7-smooth lengths up to 16384 run as ONE kernel whose LDS exchange moves the real and the imaginary
     plane one after the other (engine.h SPLIT): all API modes vs the oracle's plan, every radix mix of the generated list."""
     planner = emu_planner(dtype)
-    sizes = [4116, 4375, 5000, 6561, 8192, 10000, 12288, 16384] + ([14406, 15625, 16200, 32768] if dtype == np.complex64 else [])
+    sizes = [4116, 4375, 5000, 6561, 8192, 10000, 12288, 16384] + ([14406, 15625, 16200, 19683, 25000, 32768] if dtype == np.complex64 else [])
     for n in sizes:
         for d in (0, 1):
             fft = planner.plan_fft(n, d)

@@ -131,10 +131,12 @@ def main_big():
     for tag, ty, prec, esz in (("f32", "float", 32, 8), ("f64", "double", 64, 16)):
         emaxes = (16, 32) if prec == 32 else (16,)
         sizes = [x for x in smooth(16384, [2, 3, 5, 7]) if x > 4096 and (x & (x - 1)) and big_schedule(x, emaxes)]
+        if prec == 32:  # f32 rows up to 32768 points still fit one workgroup's LDS through the split exchange (<= 132 KB)
+            sizes += [x for x in smooth(32768, [2, 3, 5, 7]) if x > 16384 and (x & (x - 1)) and big_schedule32(x)]
         for ci in range(nfiles):
             lines = []
             for n in sizes[ci::nfiles]:
-                rad, tpf = big_schedule(n, emaxes)
+                rad, tpf = big_schedule(n, emaxes) if n <= 16384 else big_schedule32(n)
                 lines.append(f"    MI_K1({ty}, {prec}, 1, true, {n}, {tpf}, {', '.join(map(str, rad))});")
             path = os.path.join(ROOT, "rustfft_amd", "csrc", f"kernels_smooth2_{tag}_{ci}.hip")
             with open(path, "w") as fh:
@@ -142,7 +144,7 @@ def main_big():
                          f"// lengths in (4096, 16384] (part {ci + 1} of {nfiles}), Complex<{ty}>.\n"
                          '#include "launch.h"\nnamespace mi355 {\n'
                          f"void register_smooth2_{tag}_{ci}(std::vector<KernelEntry>& reg) {{\n" + "\n".join(lines) + "\n}\n}  // namespace mi355\n")
-        print(len(sizes), "lengths in (4096, 16384],", tag)
+        print(len(sizes), "lengths in (4096, 16384] (f32: 32768],", tag)
 
 
 def main():
