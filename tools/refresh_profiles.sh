@@ -20,7 +20,7 @@ cp $(find /tmp/prof_c3 -name "*kernel_stats.csv" | head -1) $OUT/bench_c3_kernel
 # 4. sweeps
 python tools/sweep.py --dtype f32 --min 1 --max 24 > $OUT/sweep_pow2_f32.jsonl 2>/dev/null
 python tools/sweep.py --dtype f64 --min 1 --max 23 > $OUT/sweep_pow2_f64.jsonl 2>/dev/null
-NP2=3,7,17,77,100,127,360,719,1000,1001,1009,1019,1200,2310,3000,4093,4099,5000,10007,44100,65537,100000,100003,1000000,1000003,1536000,7340032
+NP2=3,7,17,77,100,127,251,360,719,1000,1001,1009,1019,1200,2310,3000,4093,4099,5000,10000,10007,19683,25000,44100,65537,100000,100003,1000000,1000003,1536000,7340032
 python tools/sweep.py --dtype f32 --sizes $NP2 > $OUT/sweep_np2_f32.jsonl 2>/dev/null
 python tools/sweep.py --dtype f64 --sizes $NP2 > $OUT/sweep_np2_f64.jsonl 2>/dev/null
 # 5. issue / stall breakdown (SQ counters, two passes each)
