@@ -59,9 +59,24 @@ def cpu_baseline(n, log):
     t = fwd.time_batch(buf, batch, 1, cores) + inv.time_batch(buf, batch, 1, cores)
     flops = 2 * batch * 5.0 * n * math.log2(n)
     log(f"cpu_baseline: {batch} transforms fwd+inv on {cores} threads in {t:.2f}s")
-    out = {"value": flops / t / 1e9, "unit": "GFLOP/s", "cores": cores, "kind": "port",
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    out = {"value": flops / t / 1e9, "unit": "GFLOP/s", "cores": cores, "kind": "port", "cpu_model": model,
            "sample": f"N=2^{int(math.log2(n))} Complex<f32>, {batch} transforms forward+inverse, {cores} caller threads sharing one plan "
-                     f"(scalar-path restatement compiled -O2 -ffp-contract=off, not the RustFFT binary)"}
+                     f"(scalar-path restatement compiled -O2 -ffp-contract=off, not the RustFFT binary; no rustc/cargo on this box)"}
+    try:  # the same restatement compiled -O3 -march=native on this host
+        tn = oracle.time_batch_native(np.complex64, n, 0, buf, batch, 1, cores)
+        ti = oracle.time_batch_native(np.complex64, n, 1, buf, batch, 1, cores)
+        if tn and ti:
+            out["native_build"] = {"value": flops / (tn + ti) / 1e9, "unit": "GFLOP/s", "flags": "-O3 -march=native -ffp-contract=off"}
+    except Exception as e:
+        log(f"native oracle build unavailable: {e}")
     try:  # external CPU yardstick asked for by SURVEY.md section 8(d): pocketfft (scipy.fft) on every core, same workload shape
         import scipy.fft
 
@@ -141,6 +156,102 @@ def side_config(args, rank, local_rank, world, dist, log):
         dist.destroy_process_group()
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without torchrun: start one process per GPU (rank i on GPU i) with the torchrun
+    environment contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) and relay rank 0's JSON line."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit(f"rank exit codes: {rcs}")
+
+
+def fill_blocks(torch, buf, batch, n, gen, rows_per_block=64):
+    """U[0,10) re/im, generated in row blocks so that the same seeded stream can be regenerated block by block later."""
+    rows = buf.view(batch, n)
+    for r0 in range(0, batch, rows_per_block):
+        torch.view_as_real(rows[r0:r0 + rows_per_block]).uniform_(0.0, 10.0, generator=gen)
+
+
+def row_energy(torch, buf, batch, n):
+    rows = buf.view(batch, n)
+    return torch.cat([(torch.view_as_real(rows[r0:r0 + 64]).double() ** 2).sum(dim=(1, 2)) for r0 in range(0, batch, 64)])
+
+
+def roundtrip_check(torch, fwd, inv, data, n, batch, seed_gen):
+    """Untimed full-batch verification on fresh data: y = ifft(fft(x)) / N against x (max abs error, relative L2) and
+    Parseval on the forward result, every row of the shard.  The input is regenerated block by block from the same seed
+    for the comparison, so no second batch-sized buffer is needed."""
+    fill_blocks(torch, data, batch, n, seed_gen())
+    e_in = row_energy(torch, data, batch, n)
+    fwd.process(data)
+    parseval = ((row_energy(torch, data, batch, n) / n - e_in).abs() / e_in).max().item()
+    inv.process(data)
+    rows = data.view(batch, n)
+    ref = torch.empty(64 * n, dtype=data.dtype, device=data.device)
+    g = seed_gen()
+    max_err, num, den = 0.0, 0.0, 0.0
+    for r0 in range(0, batch, 64):
+        cnt = min(64, batch - r0)
+        blk = ref[: cnt * n].view(cnt, n)
+        torch.view_as_real(blk).uniform_(0.0, 10.0, generator=g)
+        d = rows[r0:r0 + cnt] * (1.0 / n) - blk
+        max_err = max(max_err, d.abs().max().item())
+        num += (d.abs().double() ** 2).sum().item()
+        den += (blk.abs().double() ** 2).sum().item()
+    return {"roundtrip_max_abs_err": max_err, "roundtrip_rel_l2": math.sqrt(num / den), "parseval_max_rel_err": parseval,
+            "what": f"untimed ifft(fft(x))/N vs x on all {batch} rows, x re/im ~ U[0,10); Parseval on the forward result"}
+
+
+def config5_nested(torch, planner, local_rank, rank, world, dist, steps, warmup, np):
+    """BASELINE config 5 (N = 2^22, 1024 transforms per GPU = 8192 over 8 GPUs), forward, immutable input: measured after the
+    headline config on the same ranks and reported inside the one JSON line (key "config5")."""
+    from rustfft_amd.sharding import reduce_max
+
+    n, batch = 1 << 22, 1024
+    fft = planner.plan_fft_forward(n)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x52555354 + 500 + rank)
+    x = torch.empty(batch * n, dtype=torch.complex64, device="cuda")
+    torch.view_as_real(x).uniform_(0.0, 10.0, generator=g)
+    y = torch.empty_like(x)
+    for _ in range(warmup):
+        fft.process_immutable_with_scratch(x, y)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fft.process_immutable_with_scratch(x, y)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = reduce_max(time.perf_counter() - t0, dist, device="cuda")
+    # per-rank parity guard: Parseval on every row of the shard, MAX-reduced (SURVEY section 8(d), C5 row)
+    ex = torch.cat([(torch.view_as_real(x.view(batch, n)[r0:r0 + 32]).double() ** 2).sum(dim=(1, 2)) for r0 in range(0, batch, 32)])
+    ey = torch.cat([(torch.view_as_real(y.view(batch, n)[r0:r0 + 32]).double() ** 2).sum(dim=(1, 2)) for r0 in range(0, batch, 32)]) / n
+    err = reduce_max(((ey - ex).abs() / ex).max().item(), dist, device="cuda")
+    kms = fft.profile_kernels(y, reps=2) if rank == 0 else []
+    alg = batch * 2 * n * 8
+    return {"workload": f"N=2^22 Complex<f32>, batch={batch} per GPU ({batch * world} total), forward, immutable input, HBM-resident",
+            "value": world * batch * 5.0 * n * 22 * steps / elapsed / 1e9, "unit": "GFLOP/s", "ms_per_step": elapsed / steps * 1e3,
+            "parseval_max_rel_err_over_ranks": err, "plan": fft.describe(),
+            "kernels": [{"kernel": nm, "ms": ms, "GBps": alg / (ms * 1e-3) / 1e9} for nm, ms in zip(fft.kernel_names(), kms)]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,7 +265,11 @@ def main():
                          "c4 N=1009 f32 x2^20; c5 N=2^22 f32 x1024 per GPU (8192 over 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
+    ap.add_argument("--no-config5", action="store_true", help="at --gpus > 1: skip the nested BASELINE config-5 measurement")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
 
     import numpy as np
     import torch
@@ -194,32 +309,61 @@ def main():
     torch.view_as_real(data).uniform_(0.0, 10.0, generator=g)
     scale0 = 2.0 ** -100
     data.mul_(scale0)
-    renorm_every = max(1, 224 // args.log2n)  # steps before magnitudes approach 2^128 (11 at N = 2^20)
+    # The transforms are unnormalised: every step multiplies the data by N.  Starting at 2^-100 the magnitudes stay finite
+    # in f32 for `span` steps (11 at N = 2^20), which covers the default warmup + steps with NO extra kernel in the timed
+    # region.  Longer runs renormalise between steps with the clock stopped (synchronised on both sides, counted in
+    # `renorm_pauses`), so the timed region contains the K forward+inverse pairs and nothing else.
+    span = max(1, 224 // args.log2n)
+    done = 0
 
-    def step(i):
+    def renorm_if_needed():
+        nonlocal done
+        if done and done % span == 0:
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            data.mul_(float(n) ** (-span))
+            torch.cuda.synchronize()
+            return time.perf_counter() - t
+        return 0.0
+
+    def step():
+        nonlocal done
         fwd.process(data)
         inv.process(data)
-        if (i + 1) % renorm_every == 0:  # only reached when warmup+steps exceeds the finite range
-            data.mul_(float(n) ** (-renorm_every))
+        done += 1
 
     for i in range(args.warmup):
-        step(i)
+        renorm_if_needed()
+        step()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    paused, pauses = 0.0, 0
     for i in range(args.steps):
-        step(args.warmup + i)
+        dt = renorm_if_needed()
+        paused += dt
+        pauses += dt > 0
+        step()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = time.perf_counter() - t0 - paused
     from rustfft_amd.sharding import reduce_max
 
     elapsed = reduce_max(elapsed, dist, device="cuda")  # MAX over ranks (RCCL all-reduce of one scalar)
-    finite = bool(torch.isfinite(torch.view_as_real(data[: 1 << 16])).all().item())
+    finite = bool(torch.isfinite(torch.view_as_real(data)).all().item())
+
+    def seed_gen():
+        gg = torch.Generator(device="cuda")
+        gg.manual_seed(0x52555354 + 100 + rank)
+        return gg
+
+    check = roundtrip_check(torch, fwd, inv, data, n, batch, seed_gen)  # untimed, every row of this rank's shard
+    for key in ("roundtrip_max_abs_err", "roundtrip_rel_l2", "parseval_max_rel_err"):
+        check[key] = reduce_max(check[key], dist, device="cuda")  # worst rank
 
     flops_per_step = world * 2 * batch * 5.0 * n * math.log2(n)
     value = flops_per_step * args.steps / elapsed / 1e9
@@ -229,11 +373,21 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"N=2^{args.log2n} Complex<f32>, batch={batch} per GPU, forward+inverse per step, in place, HBM-resident",
-                   "plan": fwd.describe(), "finite": finite},
+                   "plan": fwd.describe(), "finite": finite, "renorm_pauses": pauses},
+        "check": check,
     }
+    if check["roundtrip_rel_l2"] > 5e-6 or check["parseval_max_rel_err"] > 1e-4 or not finite:
+        out["check"]["FAILED"] = True
+    if world > 1 and not args.no_config5:
+        del data
+        torch.cuda.empty_cache()
+        data = None
+        out["config5"] = config5_nested(torch, planner, local_rank, rank, world, dist, max(2, args.steps // 2), 1, np)
     if rank == 0:
         # per-kernel durations with HIP events on the launch stream, same buffers, same step count
         torch.cuda.synchronize()
+        if data is None:
+            data = torch.zeros(batch * n, dtype=torch.complex64, device="cuda")
         ms_f = fwd.profile_kernels(data, reps=args.steps)
         ms_i = inv.profile_kernels(data, reps=args.steps)
         names = fwd.kernel_names()

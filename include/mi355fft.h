@@ -57,7 +57,9 @@ int mi355fft_init(int device);
  * Replaces `FftPlanner::plan_fft(len, direction) -> Arc<dyn Fft<T>>` (src/plan.rs:101-111, 289-295) for
  * the HIP back-end: builds the device twiddle/index tables and picks the kernel sequence.
  * precision: 32 (Complex<f32>) or 64 (Complex<f64>).  The plan is bound to the device current at
- * creation.  `Drop for HipFft<T>` calls mi355fft_plan_destroy. */
+ * creation: its tables live there, and every process_* call runs there whatever device is current in
+ * the calling thread (the call switches and restores it).  `Drop for HipFft<T>` calls
+ * mi355fft_plan_destroy, which waits for the device to drain before freeing tables and workspaces. */
 int mi355fft_plan_create(size_t len, int direction, int precision, mi355fft_plan** out_plan);
 int mi355fft_plan_destroy(mi355fft_plan* plan);
 
@@ -91,7 +93,10 @@ int mi355fft_process_immutable_host(const mi355fft_plan* plan, const void* input
  * Same three modes on HBM-resident buffers (16-byte aligned device pointers), asynchronous on `stream`
  * (a hipStream_t passed as void*; NULL = the default stream).  `batch` = number of length-len sequences.
  * The large-N passes use a plan-owned HBM workspace of batch*len elements for in-place calls
- * (allocated on first use, grown on demand, protected for concurrent callers). */
+ * (allocated on first use, grown on demand).  Concurrent callers: a multi-pass call holds a
+ * per-(plan, stream) lock while it enqueues its passes, so calls that share a plan AND a stream run
+ * their pass sequences back to back in stream order; calls on different streams proceed in parallel
+ * with their own workspaces. */
 int mi355fft_process_inplace_dev(const mi355fft_plan* plan, void* buffer, size_t batch, void* stream);
 int mi355fft_process_outofplace_dev(const mi355fft_plan* plan, void* input, void* output, size_t batch, void* stream);
 int mi355fft_process_immutable_dev(const mi355fft_plan* plan, const void* input, void* output, size_t batch,
@@ -107,6 +112,12 @@ int mi355fft_profile_inplace_dev(const mi355fft_plan* plan, void* buffer, size_t
                                  float* ms_per_kernel, int n_kernels);
 /* Tunables (0 = library default): transforms per workspace chunk of the multi-pass path. */
 int mi355fft_plan_set_chunk_batch(mi355fft_plan* plan, size_t chunk_batch);
+/* Plan-owned HBM workspaces (one per stream the plan was used on, kept for reuse): bytes currently held, and a
+ * release of all of them (waits for the device first; returns the bytes freed through *freed, which may be NULL).
+ * The reference's counterpart is the scratch the caller owns (src/lib.rs:259-277); here it lives in HBM, so a
+ * long-lived plan used on many transient streams can hand the memory back without being destroyed. */
+size_t mi355fft_plan_workspace_bytes(const mi355fft_plan* plan);
+int mi355fft_plan_trim_workspaces(mi355fft_plan* plan, size_t* freed);
 
 const char* mi355fft_strerror(int status);
 /* Detailed message of the calling thread's most recent failure (the reference's panic text for the

@@ -264,3 +264,32 @@ def compute_twiddle(dtype, index, fft_len, direction=FORWARD):
     re, im = ctypes.c_double(), ctypes.c_double()
     lib().rfo_compute_twiddle(_prec_of(dtype), index, fft_len, direction, ctypes.byref(re), ctypes.byref(im))
     return complex(re.value, im.value)
+
+
+def time_batch_native(dtype, length, direction, buffer, batch, reps=1, threads=1):
+    """The same restatement compiled `-O3 -march=native` ON THE MACHINE THAT RUNS IT (SURVEY section 8(d) asks for this
+    figure next to the -O2 one), timed the way Fft.time_batch times the default build.  The library goes to the
+    temporary directory: it is host-specific and never travels.  Returns seconds, or None when g++ is unavailable."""
+    import tempfile
+
+    out = os.path.join(tempfile.gettempdir(), "librustfft_oracle_native.so")
+    try:
+        if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(os.path.join(_HERE, "rustfft_scalar.hpp")):
+            subprocess.check_call(["g++", "-O3", "-march=native", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-pthread",
+                                   "-o", out, os.path.join(_HERE, "rustfft_oracle_capi.cpp")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        L = ctypes.CDLL(out)
+    except Exception:
+        return None
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    L.rfo_plan.restype = vp
+    L.rfo_plan.argtypes = [ci, sz, ci]
+    L.rfo_free.argtypes = [vp]
+    L.rfo_time_batch.restype = ctypes.c_double
+    L.rfo_time_batch.argtypes = [vp, vp, sz, ci, ci]
+    h = L.rfo_plan(_prec_of(dtype), length, direction)
+    if not h:
+        return None
+    try:
+        return float(L.rfo_time_batch(vp(h), buffer.ctypes.data_as(vp), batch, reps, threads))
+    finally:
+        L.rfo_free(vp(h))

@@ -8,12 +8,15 @@ namespace mi355 {
 namespace backend {
 int device_count();
 int init(int device);              // 0 on success
+int current_device();              // HIP's current device of the calling thread, -1 on failure
+int set_device(int device);        // 0 on success
 void* dmalloc(size_t bytes);       // nullptr on failure
 void dfree(void* p);
 int h2d(void* d, const void* h, size_t bytes, void* stream);
 int d2h(void* h, const void* d, size_t bytes, void* stream);
 int d2d(void* dst, const void* src, size_t bytes, void* stream);
 int sync(void* stream);
+int sync_device();                // drains every stream of the current device
 int check_launch();                // last launch error -> 0 / nonzero
 std::string last_error();
 void* event_create();

@@ -30,6 +30,12 @@ int init(int device) {
     }
     return fail(hipSetDevice(device));
 }
+int current_device() {
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) return -1;
+    return d;
+}
+int set_device(int device) { return fail(hipSetDevice(device)); }
 void* dmalloc(size_t bytes) {
     void* p = nullptr;
     if (fail(hipMalloc(&p, bytes ? bytes : 16))) return nullptr;
@@ -42,6 +48,7 @@ int h2d(void* d, const void* h, size_t bytes, void* s) { return fail(hipMemcpyAs
 int d2h(void* h, const void* d, size_t bytes, void* s) { return fail(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)s)); }
 int d2d(void* dst, const void* src, size_t bytes, void* s) { return fail(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s)); }
 int sync(void* s) { return fail(hipStreamSynchronize((hipStream_t)s)); }
+int sync_device() { return fail(hipDeviceSynchronize()); }
 int check_launch() { return fail(hipGetLastError()); }
 std::string last_error() { return g_err; }
 void* event_create() {

@@ -225,6 +225,14 @@ int mi355fft_plan_set_chunk_batch(mi355fft_plan* plan, size_t chunk_batch) {
     return MI355FFT_OK;
 }
 
+size_t mi355fft_plan_workspace_bytes(const mi355fft_plan* plan) { return plan ? const_cast<Plan&>(plan->p).workspace_bytes() : 0; }
+int mi355fft_plan_trim_workspaces(mi355fft_plan* plan, size_t* freed) {
+    if (!plan) return set_err(MI355FFT_ERR_INVALID_ARG, "null plan");
+    const size_t n = plan->p.trim_workspaces();
+    if (freed) *freed = n;
+    return MI355FFT_OK;
+}
+
 const char* mi355fft_strerror(int status) {
     switch (status) {
         case MI355FFT_OK: return "ok";

@@ -373,6 +373,12 @@ template <class L> struct ElemSrc {
 };
 template <class L> MI_HD ElemSrc<L> elem_src(L l) { return ElemSrc<L>{l}; }
 
+// A source may go one step further and take over the whole first load of a thread -- every butterfly of sub-pass 0 at
+// once -- by declaring `static constexpr bool kLoadsAll = true` and implementing load_all<S>(f, u, v): the column-tile
+// passes share the inter-pass twiddle powers across a thread's butterflies that way.
+template <class SRC, class = void> struct src_loads_all : std::false_type {};
+template <class SRC> struct src_loads_all<SRC, std::enable_if_t<SRC::kLoadsAll>> : std::true_type {};
+
 // register array length an executor must provide per thread
 template <class S, bool SPLIT> constexpr int regs_needed() { return S::emax(); }
 // LDS bytes one workgroup needs
@@ -390,14 +396,18 @@ MI_HD void wg_fft(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC src, DS
     ex.for_threads([&](int tid, cx<T>* v) {
         int f, u;
         map_tid<MIN, F, S::TPF>(tid, f, u);
-        static_for<0, BPT0>([&](auto M_) {
-            constexpr int m = M_;
-            const int b = u + m * S::TPF;
-            if ((m + 1) * S::TPF <= NB0 || b < NB0) {
-                src.template bfly<R0>(f, b, NB0, v + m * R0);
-            }
-            if constexpr (BPT0 > 1 && R0 * BPT0 > 16) MI_SCHED_FENCE();
-        });
+        if constexpr (src_loads_all<SRC>::value) {
+            src.template load_all<S>(f, u, v);
+        } else {
+            static_for<0, BPT0>([&](auto M_) {
+                constexpr int m = M_;
+                const int b = u + m * S::TPF;
+                if ((m + 1) * S::TPF <= NB0 || b < NB0) {
+                    src.template bfly<R0>(f, b, NB0, v + m * R0);
+                }
+                if constexpr (BPT0 > 1 && R0 * BPT0 > 16) MI_SCHED_FENCE();
+            });
+        }
     });
     if constexpr (SRC_IN_LDS) ex.barrier();
     wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, 0, TWREG, TWSTAGE>(ex, lds_raw, tw, src, dst);

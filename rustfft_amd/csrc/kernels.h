@@ -97,54 +97,64 @@ MI_HD void k1bs_body(X& ex, const BluesteinParams<T>& p, long long block, void* 
 // 32-lane group must fall on the banks the columns leave free
 constexpr int k2_pitch_mod(int f) { return f < 32 ? 32 / f : 1; }
 
-// Source of a large-N pass: F-element row segments, times the inter-pass twiddle w_Q^{c j} (Q = S R,
-// c = B mod S, j = row).  A thread's butterfly needs rows j = b + k nb, k = 0..R-1, so
-//     w^{c j} = w^{c b} * (w^{c nb})^k :
-// two two-level table look-ups (base and step) per butterfly, then step^(2^i) by squaring and each power
-// through at most log2(R) multiplications.  This replaces 2 R divergent table gathers per butterfly.
+// Source of a large-N pass: F-element row segments, times the inter-pass twiddle w_Q^{c j} (Q = S R, c = B mod S,
+// j = row).  A thread (column c, slot u) holds the rows j = u + m TPF + k NB (butterfly m, input k), so its factors are
+//     w^{c j} = [w^{c u} (w^{c TPF})^m] * (w^{c NB})^k = B_m P^k :
+// three two-level table look-ups per THREAD (B_0, the butterfly step Q = w^{c TPF} and P), the powers P^2, P^3, P^4
+// shared by all butterflies of the thread, and per butterfly groups of four inputs: T, T P, T P^2, T P^3 with the group
+// base T advancing by P^4.  2R + 1 complex multiplications per butterfly, a dependency chain R/4 + BPT long (rounding
+// error ~ sqrt of that times eps), six table gathers per thread.  (History: 2 R divergent gathers per butterfly ran the
+// later passes at 3.3 TB/s; base + step per butterfly with a depth-first power walk -- 16 gathers per thread -- at
+// 4.4 - 4.8; divergent 8-byte gathers cost the L1 one cycle per lane, the row segments one per 16 lanes.)
 template <class T, bool FIRST, int ABL = 0> struct K2Src {
+    static constexpr bool kLoadsAll = true;
     const cx<T>* MI_RESTRICT in;
-    long long M, b0, bmod0;
+    unsigned M, b0, bmod0;
     T sgn_in;
     const cx<T>* MI_RESTRICT tlo;
     const cx<T>* MI_RESTRICT thi;
-    int hshift, lmask, dbg;
+    int hshift, lmask;
     MI_HD cx<T> lut(unsigned e) const { return tlo[e & (unsigned)lmask] * thi[e >> hshift]; }
-    // K: index reached so far, J0: lowest bit position still allowed to be added
-    template <int R, int LOG, int K, int J0> MI_HD static void apply_tw(cx<T>* v, cx<T> w, const cx<T>* sp) {
-        v[K] = v[K] * w;
-        static_for<J0, LOG>([&](auto J_) {
-            constexpr int j = J_;
-            if constexpr (K + (1 << j) < R) apply_tw<R, LOG, K + (1 << j), j + 1>(v, w * sp[j], sp);
-        });
-    }
-    template <int R, class TT> MI_HD void bfly(int f, int b, int nb, cx<TT>* v) const {
+    template <class S> MI_HD void load_all(int f, int u, cx<T>* v) const {
+        constexpr int R = S::R[0], NB = S::nb(0), BPT = S::bpt(0), TPF = S::TPF;
+        static_assert(NB % TPF == 0 && NB == BPT * TPF, "column-tile schedules fill every thread");
         // 32-bit element offsets from the (workgroup-uniform) transform base: one VGPR per address instead of two
-        const unsigned col = (unsigned)(b0 + f), m32 = (unsigned)M;
-        static_for<0, R>([&](auto K_) {
-            constexpr int k = K_;
-            cx<T> x;
-            if constexpr ((ABL & 16) != 0)
-                x = ld_nt(in + (col + (unsigned)(b + k * nb) * m32));
-            else
-                x = in[col + (unsigned)(b + k * nb) * m32];
-            x.im *= sgn_in;
-            v[k] = x;
+        const unsigned col = b0 + (unsigned)f;
+        static_for<0, BPT>([&](auto M_) {
+            constexpr int m = M_;
+            static_for<0, R>([&](auto K_) {
+                constexpr int k = K_;
+                const unsigned row = (unsigned)(u + m * TPF + k * NB);
+                if constexpr ((ABL & 16) != 0)
+                    v[m * R + k] = ld_nt(in + (col + row * M));
+                else
+                    v[m * R + k] = in[col + row * M];
+            });
         });
-        if constexpr (!FIRST && !(ABL & 1)) {
-            const unsigned c = (unsigned)(bmod0 + f);
-            constexpr int LOG = (R > 16) ? 5 : (R > 8) ? 4 : (R > 4) ? 3 : (R > 2) ? 2 : (R > 1) ? 1 : 0;
-            cx<T> sp[LOG > 0 ? LOG : 1];
-            if constexpr (LOG > 0) {
-                sp[0] = lut(c * (unsigned)nb);
-                static_for<1, LOG>([&](auto I_) {
-                    constexpr int i = I_;
-                    sp[i] = sp[i - 1] * sp[i - 1];
+        if constexpr (FIRST || (ABL & 1)) {
+            static_for<0, BPT * R>([&](auto I_) { v[decltype(I_)::value].im *= sgn_in; });
+        } else {
+            const unsigned c = bmod0 + (unsigned)f;
+            const cx<T> s1 = lut(c * (unsigned)NB);
+            cx<T> tb = lut(c * (unsigned)u), q = tb;
+            if constexpr (BPT > 1) q = lut(c * (unsigned)TPF);
+            const cx<T> s2 = s1 * s1, s3 = s2 * s1, s4 = s2 * s2;
+            static_for<0, BPT>([&](auto M_) {
+                constexpr int m = M_;
+                cx<T>* x = v + m * R;
+                cx<T> t = tb;
+                static_for<0, R / 4>([&](auto H_) {
+                    constexpr int h = H_;
+                    static_for<0, 4>([&](auto L_) { x[4 * h + decltype(L_)::value].im *= sgn_in; });
+                    x[4 * h] = x[4 * h] * t;
+                    x[4 * h + 1] = x[4 * h + 1] * (t * s1);
+                    x[4 * h + 2] = x[4 * h + 2] * (t * s2);
+                    x[4 * h + 3] = x[4 * h + 3] * (t * s3);
+                    if constexpr (h + 1 < R / 4) t = t * s4;
                 });
-            }
-            // depth-first walk over the bits of k: w_{k + 2^j} = w_k * step^(2^j).  At most log2(R)+1 twiddles are
-            // live at a time (a flat table of R of them is what pushed the 32-values-per-thread tiles into spills).
-            apply_tw<R, LOG, 0, 0>(v, lut(c * (unsigned)b), sp);
+                if constexpr (m + 1 < BPT) tb = tb * q;
+                if constexpr (BPT > 1 && R * BPT > 16) MI_SCHED_FENCE();
+            });
         }
     }
 };
@@ -152,32 +162,35 @@ template <class T, bool FIRST, int ABL = 0> struct K2Src {
 template <class T, class S, int F, bool FIRST, bool SPLIT, int ABL = 0, class X>
 MI_HD void k2_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     constexpr int R = S::N;
-    // XCD-aware tile order.  Workgroup b is dispatched to XCD b % 8 (MI355X_MICROARCH.md, observed, used
-    // for speed only).  When a tile's row segment is narrower than the 128-byte L2 line (pair = 128 /
-    // (F * sizeof(C)) > 1), the `pair` tiles sharing each line are given to the same XCD back to back, so the
-    // line is fetched into one L2 once instead of into several L2s.
-    if (p.pair > 1) {
-        const long long grp = 8LL * p.pair;
-        block = (block / grp) * grp + (block % 8) * p.pair + (block / 8) % p.pair;
+    // XCD-aware tile order.  Workgroup b is dispatched to XCD b % 8 (MI355X_MICROARCH.md, observed, used for speed
+    // only).  Within every aligned group of 8 << xq consecutive workgroups (all tiles of one transform), XCD x takes the
+    // tiles whose index has x in bits [xp, xp + 3): each XCD then streams runs of 2^xp ADJACENT tiles, and its requests
+    // spread over the address bits that select L2 / memory channels instead of sharing them.  Measured with the tile
+    // skeleton (tools/membench/skel.hip, 1024 x 16 tiles): identity order 5.1 / 4.9 TB/s (first / later pass shape),
+    // x at address bits 9-11 5.6 / 5.5.  For tiles narrower than a 128-byte line this also keeps the tiles that share
+    // a line on one XCD back to back (one L2 fetches the line once).
+    if (p.xq > 0) {
+        const int r = (int)(block & ((8LL << p.xq) - 1)), x = r & 7, i = r >> 3;
+        const int t = ((i >> p.xp) << (p.xp + 3)) | (x << p.xp) | (i & ((1 << p.xp) - 1));
+        block += t - r;
     }
-    const long long g = block / p.tiles_per_fft;
-    const long long tile = block % p.tiles_per_fft;
-    const long long b0 = tile * F;
+    // M / F and S are powers of two for these plans: shifts, not 64-bit divisions (a 64-bit division is ~150 dependent
+    // scalar instructions in front of the first load of the workgroup)
+    const long long g = block >> p.tiles_shift;
+    const unsigned tile = (unsigned)(block & ((1LL << p.tiles_shift) - 1));
+    const unsigned b0 = tile * (unsigned)F;
     const cx<T>* MI_RESTRICT in = p.in + g * p.n;
     cx<T>* MI_RESTRICT out = p.out + g * p.n;
-    const long long M = p.m, Sg = p.s;
-    const T sgn_in = p.sgn_in, sgn_out = p.sgn_out;
-    const cx<T>* MI_RESTRICT tlo = p.tlo;
-    const cx<T>* MI_RESTRICT thi = p.thi;
-    const int hshift = p.hshift, lmask = p.lmask;
+    const unsigned M = (unsigned)p.m, s32 = (unsigned)p.s;
+    const T sgn_out = p.sgn_out;
     // a tile never straddles a multiple of S (F | S whenever S > 1), so B div S is tile-uniform
-    const long long bdiv = FIRST ? 0 : (b0 / Sg);
-    const long long bmod0 = FIRST ? 0 : (b0 % Sg);
-    const unsigned obase = (unsigned)(bdiv * Sg * R + bmod0), s32 = (unsigned)Sg;
-    K2Src<T, FIRST, ABL> src{in, M, b0, bmod0, sgn_in, tlo, thi, hshift, lmask, p.dbg};
+    const unsigned bdiv = FIRST ? 0u : (b0 >> p.s_shift);
+    const unsigned bmod0 = FIRST ? 0u : (b0 & (s32 - 1u));
+    const unsigned obase = bdiv * s32 * (unsigned)R + bmod0;
+    K2Src<T, FIRST, ABL> src{in, M, b0, bmod0, p.sgn_in, p.tlo, p.thi, p.hshift, p.lmask};
     auto dst = [=](int f, int k, cx<T> x) {
         x.im *= sgn_out;
-        cx<T>* o = FIRST ? out + ((unsigned)(b0 + f) * (unsigned)R + (unsigned)k) : out + (obase + (unsigned)f + (unsigned)k * s32);
+        cx<T>* o = FIRST ? out + ((b0 + (unsigned)f) * (unsigned)R + (unsigned)k) : out + (obase + (unsigned)f + (unsigned)k * s32);
         if constexpr ((ABL & 32) != 0)
             st_nt(o, x);
         else

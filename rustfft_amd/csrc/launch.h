@@ -478,13 +478,21 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
 }
 #endif
 
+// Variant (V) and ablation (ABL) instantiations are tuning aids: compiled only with -DMI355_TUNING, so the shipped
+// library contains no kernel that is wrong by design and no alternative tiling an environment variable could select.
+#if defined(MI355_TUNING)
 #define MI_K1ABL(V, ABL, T, PREC, F, SPLIT, ...)                                                               \
     reg.push_back(make_k1<T, Sched<__VA_ARGS__>, F, SPLIT, ABL>(PREC, "k1<" #__VA_ARGS__ ">xF" #F "abl" #ABL)); \
     reg.back().variant = V
 #define MI_K1V(V, T, PREC, F, SPLIT, ...)                                                       \
     reg.push_back(make_k1<T, Sched<__VA_ARGS__>, F, SPLIT>(PREC, "k1<" #__VA_ARGS__ ">xF" #F "v" #V)); \
     reg.back().variant = V
+#else
+#define MI_K1ABL(V, ABL, T, PREC, F, SPLIT, ...) (void)0
+#define MI_K1V(V, T, PREC, F, SPLIT, ...) (void)0
+#endif
 #define MI_K1(T, PREC, F, SPLIT, ...) reg.push_back(make_k1<T, Sched<__VA_ARGS__>, F, SPLIT>(PREC, "k1<" #__VA_ARGS__ ">xF" #F))
+#if defined(MI355_TUNING)
 #define MI_K2V(V, T, PREC, F, SPLIT, ...)                                                                   \
     reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, true, SPLIT>(PREC, "k2first<" #__VA_ARGS__ ">xF" #F "v" #V));  \
     reg.back().variant = V;                                                                                  \
@@ -495,6 +503,10 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
     reg.back().variant = V;                                                                                  \
     reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, false, SPLIT, ABL>(PREC, "k2later<" #__VA_ARGS__ ">xF" #F "abl" #ABL)); \
     reg.back().variant = V
+#else
+#define MI_K2V(V, T, PREC, F, SPLIT, ...) (void)0
+#define MI_K2ABL(V, ABL, T, PREC, F, SPLIT, ...) (void)0
+#endif
 #define MI_K2(T, PREC, F, SPLIT, ...)                                                                  \
     reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, true, SPLIT>(PREC, "k2first<" #__VA_ARGS__ ">xF" #F)); \
     reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, false, SPLIT>(PREC, "k2later<" #__VA_ARGS__ ">xF" #F))
@@ -517,12 +529,20 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
     reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, false, 3>(PREC, "k2glast_chirp<" #__VA_ARGS__ ">xF" #F))
 // Bluestein bodies take the linear exchange layout (SchedL): 164 -> 124 VGPRs for the power-of-two inner lengths
 #define MI_BS(T, PREC, F, ...) reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F))
+#if defined(MI355_TUNING)
 #define MI_BSV(V, T, PREC, F, ...)                                                                    \
     reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F "v" #V)); \
     reg.back().variant = V
+#else
+#define MI_BSV(V, T, PREC, F, ...) (void)0
+#endif
 #define MI_RADER(T, PREC, F, MODE, ...) reg.push_back(make_rader<T, Sched<__VA_ARGS__>, F, MODE>(PREC, "rader<" #__VA_ARGS__ ">xF" #F "m" #MODE))
+#if defined(MI355_TUNING)
 #define MI_RADERV(V, T, PREC, F, MODE, ...)                                                                   \
     reg.push_back(make_rader<T, Sched<__VA_ARGS__>, F, MODE>(PREC, "rader<" #__VA_ARGS__ ">xF" #F "m" #MODE "v" #V)); \
     reg.back().variant = V
+#else
+#define MI_RADERV(V, T, PREC, F, MODE, ...) (void)0
+#endif
 
 }  // namespace mi355

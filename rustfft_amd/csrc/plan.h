@@ -34,6 +34,17 @@ struct Workspace {
     size_t bytes = 0;
 };
 
+// Per-(plan, stream) execution slot.  `launch_mutex` is held for the WHOLE enqueue sequence of a multi-pass call
+// (workspace lookup, growth and every pass launch), so two host threads sharing one plan on one stream cannot
+// interleave their passes; stream order then makes the shared workspace safe (A's passes all precede B's).  Callers
+// on different streams get different slots and run concurrently.  Growth synchronises on the stream of the call that
+// asks for it (a live handle by construction); the plan's destructor drains the whole device instead of the cached
+// stream handles, which the caller may have destroyed by then.
+struct StreamSlot {
+    std::mutex launch_mutex;
+    Workspace ws;
+};
+
 // per-kernel event hooks for mi355fft_profile_inplace_dev
 struct Tracer {
     virtual ~Tracer() {}
@@ -49,15 +60,21 @@ struct Plan {
     std::vector<void*> device_allocs;
     size_t chunk_batch = 0;
     int dbg = 0;
+    int device = -1;  // HIP device the tables live on (the device current at creation)
     std::mutex ws_mutex;
-    std::map<void*, Workspace> workspaces;  // one HBM workspace per stream
+    std::map<void*, std::unique_ptr<StreamSlot>> slots;  // one execution slot (HBM workspace) per stream
     std::mutex host_mutex;                  // serialises the host-slice staging path
     Workspace stage_a, stage_b;
     std::unique_ptr<Plan> inner;  // PLAN_BLUESTEIN_LARGE: forward power-of-two plan of the padded length M
 
     ~Plan();
     std::string describe() const;
-    void* workspace_for(void* stream, size_t bytes);
+    StreamSlot& slot_for(void* stream);
+    // called with slot.launch_mutex held
+    void* workspace_in(StreamSlot& slot, size_t bytes, void* stream);
+    // Bytes of plan-owned HBM workspace currently cached / released by trim (mi355fft_plan_trim_workspaces)
+    size_t workspace_bytes();
+    size_t trim_workspaces();
 };
 
 int build_plan(Plan& plan);

@@ -98,6 +98,15 @@ class Fft:
     def set_chunk_batch(self, chunk_batch):
         self._check(self._lib.mi355fft_plan_set_chunk_batch(self._h, int(chunk_batch)))
 
+    def workspace_bytes(self):
+        """HBM the plan currently holds as per-stream workspaces."""
+        return int(self._lib.mi355fft_plan_workspace_bytes(self._h))
+
+    def trim_workspaces(self):
+        freed = ctypes.c_size_t(0)
+        self._check(self._lib.mi355fft_plan_trim_workspaces(self._h, ctypes.byref(freed)))
+        return int(freed.value)
+
     # ---- helpers -------------------------------------------------------------------------------------
     def _check(self, rc):
         if rc != 0:

@@ -10,6 +10,8 @@ namespace mi355 {
 namespace backend {
 int device_count() { return 1; }
 int init(int) { return 0; }
+int current_device() { return 0; }
+int set_device(int) { return 0; }
 void* dmalloc(size_t bytes) {
     void* p = nullptr;
     if (posix_memalign(&p, 64, bytes ? bytes : 64)) return nullptr;
@@ -21,6 +23,7 @@ int h2d(void* d, const void* h, size_t b, void*) { memcpy(d, h, b); return 0; }
 int d2h(void* h, const void* d, size_t b, void*) { memcpy(h, d, b); return 0; }
 int d2d(void* dst, const void* src, size_t b, void*) { memmove(dst, src, b); return 0; }
 int sync(void*) { return 0; }
+int sync_device() { return 0; }
 int check_launch() { return 0; }
 std::string last_error() { return "emu"; }
 void* event_create() { return (void*)1; }

@@ -111,7 +111,7 @@ def test_config2_device_resident_2p20(planners, oracle):
 
 
 def test_full_size_properties_2p22(planners):
-    """N = 2^22 (config 5's length, three-pass plan): impulse -> complex exponential, constant -> delta,
+    """N = 2^22 (config 5's length, two 2048-row passes): impulse -> complex exponential, constant -> delta,
     Parseval, on a 16-row batch."""
     import torch
 
@@ -192,6 +192,136 @@ def test_concurrent_process_on_one_plan(planners, oracle):
         want = inputs[t].copy()
         ref.process(want)
         assert compare_vectors(want, results[t])
+
+
+@pytest.mark.parametrize("log2n,same_stream", [(17, True), (17, False), (20, True), (20, False)])
+def test_concurrent_device_calls_share_a_multipass_plan(planners, oracle, log2n, same_stream):
+    """examples/concurrency.rs:9-30 on the DEVICE path: four host threads share one two-pass plan (plan-owned HBM
+    workspace) with their own HBM buffers and DIFFERENT batch sizes -- once all on torch's default stream (their pass
+    sequences must not interleave and a workspace growth must not free a buffer another call still uses), once on
+    per-thread streams (separate workspaces, true overlap).  Every row is compared with the oracle."""
+    import torch
+
+    n = 1 << log2n
+    fft = planners[np.dtype(np.complex64)].plan_fft_forward(n)
+    assert len(fft.kernel_names()) >= 2, fft.describe()
+    fft.trim_workspaces()  # start from no workspace so that the growth path is exercised under contention
+    ref = oracle.plan(np.complex64, n, 0)
+    batches = [1, 3, 2, 5]
+    inputs = {t: random_signal(n * batches[t], np.complex64, seed=500 + t) for t in range(4)}
+    results, errors = {}, []
+    start = threading.Barrier(4)
+
+    def work(t):
+        try:
+            torch.cuda.set_device(0)
+            stream = torch.cuda.current_stream() if same_stream else torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                x = torch.from_numpy(inputs[t]).cuda()
+                start.wait()
+                last = None
+                for _ in range(6):
+                    y = x.clone()
+                    fft.process(y)
+                    last = y
+                stream.synchronize()
+                results[t] = last.cpu().numpy()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    for t in range(4):
+        want = inputs[t].copy()
+        ref.process(want)
+        assert compare_vectors(want, results[t]), (t, mean_abs_err(want, results[t]))
+        assert rel_l2(results[t], numpy_fft(inputs[t], n, False)) < REL[np.dtype(np.complex64)], t
+    assert fft.workspace_bytes() >= n * 8
+    assert fft.trim_workspaces() >= n * 8 and fft.workspace_bytes() == 0
+
+
+def test_config5_rows_vs_oracle_2p22(planners, oracle):
+    """BASELINE config 5's per-GPU length (N = 2^22 f32, two 2048-row passes): sampled rows of a 6-row HBM-resident
+    batch against the oracle's Radix4 and numpy complex128, both directions."""
+    import torch
+
+    n, batch = 1 << 22, 6
+    planner = planners[np.dtype(np.complex64)]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x52555354 + 5)
+    x = torch.empty(batch * n, dtype=torch.complex64, device="cuda")
+    torch.view_as_real(x).uniform_(0.0, 10.0, generator=g)
+    for d in (0, 1):
+        fft = planner.plan_fft(n, d)
+        assert fft.describe().count("k2") == 2, fft.describe()
+        y = x.clone()
+        fft.process(y)
+        torch.cuda.synchronize()
+        ref = oracle.plan(np.complex64, n, d)
+        for row in (0, 2, 3, 5):
+            xr = x[row * n:(row + 1) * n].cpu().numpy()
+            got = y[row * n:(row + 1) * n].cpu().numpy()
+            want = xr.copy()
+            ref.process(want)
+            assert compare_vectors(want, got), (d, row)
+            assert rel_l2(got, numpy_fft(xr, n, d == 1)) < REL[np.dtype(np.complex64)], (d, row)
+
+
+def test_config2_full_batch_1024(planners, oracle):
+    """BASELINE config 2 at its FULL size (N = 2^20 f32, batch 1024 = 8 GiB in HBM, forward then inverse in place):
+    rows sampled across the whole batch against the oracle, and the round trip ifft(fft(x)) = N x on every row."""
+    import torch
+
+    n, batch = 1 << 20, 1024
+    planner = planners[np.dtype(np.complex64)]
+    fwd, inv = planner.plan_fft_forward(n), planner.plan_fft_inverse(n)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x52555354 + 22)
+    x = torch.empty(batch * n, dtype=torch.complex64, device="cuda")
+    torch.view_as_real(x).uniform_(0.0, 10.0, generator=g)
+    rows = (0, 1, 511, 512, 777, 1023)
+    keep = {r: x[r * n:(r + 1) * n].cpu().numpy() for r in rows}
+    checksum = torch.view_as_real(x).view(batch, -1).sum(dim=1, dtype=torch.float64)
+    fwd.process(x)
+    torch.cuda.synchronize()
+    ref = oracle.plan(np.complex64, n, 0)
+    for r in rows:
+        got = x[r * n:(r + 1) * n].cpu().numpy()
+        want = keep[r].copy()
+        ref.process(want)
+        assert compare_vectors(want, got), r
+        assert rel_l2(got, numpy_fft(keep[r], n, False)) < REL[np.dtype(np.complex64)], r
+    inv.process(x)
+    torch.cuda.synchronize()
+    x.mul_(1.0 / n)
+    for r in rows:
+        assert rel_l2(x[r * n:(r + 1) * n].cpu().numpy(), keep[r]) < 2e-6, r
+    # every row: its element sum survives the round trip (a mis-addressed or skipped tile anywhere in the batch breaks it)
+    after = torch.view_as_real(x).view(batch, -1).sum(dim=1, dtype=torch.float64)
+    assert ((after - checksum).abs() / checksum.abs()).max().item() < 1e-5
+
+
+def test_environment_cannot_change_results(planners, oracle):
+    """The shipped library reads no environment variable (tuning knobs and ablation kernels exist only in
+    -DMI355_TUNING builds): plans created under MI355FFT_VARIANT / MI355FFT_DBG still give the reference's results."""
+    import rustfft_amd
+
+    n = 1 << 20
+    x = random_signal(n, np.complex64)
+    want = x.copy()
+    oracle.plan(np.complex64, n, 0).process(want)
+    for var, val in (("MI355FFT_VARIANT", "5"), ("MI355FFT_VARIANT", "8"), ("MI355FFT_DBG", "1"), ("MI355FFT_MAXR", "256")):
+        os.environ[var] = val
+        try:
+            fft = rustfft_amd.FftPlanner(np.complex64).plan_fft_forward(n)  # a fresh planner: no cached plan
+            y = x.copy()
+            fft.process(y)
+            assert "abl" not in fft.describe() and compare_vectors(want, y), (var, val, fft.describe())
+            assert rel_l2(y, numpy_fft(x, n, False)) < REL[np.dtype(np.complex64)], (var, val)
+        finally:
+            del os.environ[var]
 
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--sizes", default="", help="comma-separated explicit lengths (overrides --min/--max)")
+    ap.add_argument("--check", action="store_true", help="relative L2 error of row 0 against numpy complex128")
     ap.add_argument("--lib", default="", help="A/B runs: load this build of libmi355fft.so instead of rustfft_amd/lib's")
     args = ap.parse_args()
     import numpy as np
@@ -41,8 +42,14 @@ def main():
         torch.view_as_real(x).uniform_(-1.0, 1.0)
         fft = planner.plan_fft_forward(n)
         fft.set_chunk_batch(args.chunk)
+        err = None
+        if args.check:
+            x0 = x[:n].cpu().numpy()
         fft.process(x)
         torch.cuda.synchronize()
+        if args.check:
+            want = np.fft.fft(x0.astype(np.complex128))
+            err = float(np.linalg.norm(x[:n].cpu().numpy() - want) / np.linalg.norm(want))
         torch.view_as_real(x).uniform_(-1.0, 1.0)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -56,7 +63,7 @@ def main():
         alg = batch * 2 * n * esz
         print(json.dumps({"n": n, "log2n": round(p, 3), "batch": batch, "ms": round(ms, 4), "gflops": round(batch * 5.0 * n * p / ms / 1e6, 1),
                           "alg_GBps": round(alg / ms / 1e6, 1), "kernel_ms": [round(k, 4) for k in kms],
-                          "kernel_GBps": [round(alg / k / 1e6, 1) if k > 0 else None for k in kms], "plan": fft.describe()}), flush=True)
+                          "kernel_GBps": [round(alg / k / 1e6, 1) if k > 0 else None for k in kms], "plan": fft.describe(), **({"rel_l2": err} if err is not None else {})}), flush=True)
         del x
 
 
