@@ -179,6 +179,21 @@ def spawn_ranks(n):
         raise SystemExit(f"rank exit codes: {rcs}")
 
 
+def selftest_spawn():
+    import torch
+    import torch.distributed as dist
+
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank)])
+    dist.all_reduce(t)
+    locals_ = [None] * world
+    dist.all_gather_object(locals_, local)
+    if rank == 0:
+        print(json.dumps({"selftest": "spawn", "n_gpus": world, "rank_sum": int(t.item()), "local_ranks": locals_}), flush=True)
+    dist.destroy_process_group()
+
+
 def fill_blocks(torch, buf, batch, n, gen, rows_per_block=64):
     """U[0,10) re/im, generated in row blocks so that the same seeded stream can be regenerated block by block later."""
     rows = buf.view(batch, n)
@@ -265,11 +280,16 @@ def main():
                          "c4 N=1009 f32 x2^20; c5 N=2^22 f32 x1024 per GPU (8192 over 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
+    ap.add_argument("--selftest-spawn", action="store_true", help="CPU self-test of the --gpus launcher (gloo): no GPU work")
+    ap.add_argument("--edges", action="store_true", help="at --gpus > 1 also time the scatter / gather edges (batch originating on rank 0)")
     ap.add_argument("--no-config5", action="store_true", help="at --gpus > 1: skip the nested BASELINE config-5 measurement")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus)
+
+    if args.selftest_spawn:
+        return selftest_spawn()
 
     import numpy as np
     import torch

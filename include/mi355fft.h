@@ -63,6 +63,44 @@ int mi355fft_init(int device);
 int mi355fft_plan_create(size_t len, int direction, int precision, mi355fft_plan** out_plan);
 int mi355fft_plan_destroy(mi355fft_plan* plan);
 
+/* Planning with the HOST planner in charge (north_star: "the planner/twiddle/cache host code stays in Rust").
+ * The reference's planner decides a Recipe per length (src/plan.rs:134-188) and its algorithm constructors
+ * compute the tables (twiddles src/twiddles.rs:6-23; Rader inner_fft_data src/algorithm/raders_algorithm.rs:87-113;
+ * Bluestein twiddles + inner_fft_multiplier src/algorithm/bluesteins_algorithm.rs:63-98).  Every field is optional:
+ *   algorithm    top-level family of the Recipe: AUTO lets the GPU planner choose (what plan_create does);
+ *                RADER = Recipe::RadersAlgorithm (prime len whose len - 1 is 13-smooth), BLUESTEIN =
+ *                Recipe::BluesteinsAlgorithm, MIXED_RADIX = Radix4 / RadixN / MixedRadix / butterfly recipes
+ *                (direct Cooley-Tukey kernels).  A family the length cannot run fails with MI355FFT_ERR_UNSUPPORTED.
+ *   twiddle_fn   the host's `twiddles::compute_twiddle(index, fft_len, direction)`: when set, EVERY table entry the
+ *                library uploads (sub-pass twiddles, inter-pass two-level tables, chirps, Rader / Bluestein
+ *                precomputation inputs) is obtained from it -- called with FORWARD direction only (the inverse
+ *                transform runs as conj(FFT(conj x)) on the device); re/im are doubles carrying values already rounded
+ *                to the plan's precision or wider.  Called on the planning thread, before plan_create_ex returns.
+ *   rader_inner_fft_data / bluestein_twiddles / bluestein_multiplier
+ *                the host's finished tables for a RADER / BLUESTEIN recipe, interleaved Complex<T> in the plan's
+ *                precision and DIRECTION (exactly the Box<[Complex<T>]> the reference algorithm objects hold).
+ *                rader: len - 1 entries, built with the smallest primitive root (src/math_utils.rs:3-20).
+ *                bluestein: len chirp entries and inner_len multiplier entries; inner_len must be an inner length this
+ *                build has a kernel for (query: mi355fft_bluestein_inner_len), else MI355FFT_ERR_INVALID_ARG.
+ * struct_size = sizeof(mi355fft_plan_options) (forward compatibility).  NULL options == mi355fft_plan_create. */
+enum { MI355FFT_ALGO_AUTO = 0, MI355FFT_ALGO_RADER = 1, MI355FFT_ALGO_BLUESTEIN = 2, MI355FFT_ALGO_MIXED_RADIX = 3 };
+typedef void (*mi355fft_twiddle_fn)(void* ctx, size_t index, size_t fft_len, double* re, double* im);
+typedef struct mi355fft_plan_options {
+    size_t struct_size;
+    int algorithm;
+    mi355fft_twiddle_fn twiddle_fn;
+    void* twiddle_ctx;
+    const void* rader_inner_fft_data;
+    const void* bluestein_twiddles;
+    const void* bluestein_multiplier;
+    size_t bluestein_inner_len;
+} mi355fft_plan_options;
+int mi355fft_plan_create_ex(size_t len, int direction, int precision, const mi355fft_plan_options* options,
+                            mi355fft_plan** out_plan);
+/* Inner (padded) transform length the GPU Bluestein path uses for `len` (0 when `len` is not planned through
+ * Bluestein under MI355FFT_ALGO_BLUESTEIN): what a host planner must size inner_fft_multiplier for. */
+size_t mi355fft_bluestein_inner_len(size_t len, int precision);
+
 /* `Length::len`, `Direction::fft_direction` (src/lib.rs:140-143, 174-177) */
 size_t mi355fft_plan_len(const mi355fft_plan* plan);
 int mi355fft_plan_direction(const mi355fft_plan* plan);

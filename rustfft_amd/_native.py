@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmi355fft.so")
 
 EXPORTS = [
-    "mi355fft_device_count", "mi355fft_init", "mi355fft_plan_create", "mi355fft_plan_destroy", "mi355fft_plan_len",
+    "mi355fft_device_count", "mi355fft_init", "mi355fft_plan_create", "mi355fft_plan_create_ex", "mi355fft_bluestein_inner_len", "mi355fft_plan_destroy", "mi355fft_plan_len",
     "mi355fft_plan_direction", "mi355fft_plan_precision", "mi355fft_scratch_len", "mi355fft_plan_describe",
     "mi355fft_process_inplace_host", "mi355fft_process_outofplace_host", "mi355fft_process_immutable_host",
     "mi355fft_process_inplace_dev", "mi355fft_process_outofplace_dev", "mi355fft_process_immutable_dev",
@@ -20,12 +20,25 @@ EXPORTS = [
 ]
 
 
+TWIDDLE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double))
+
+
+class PlanOptions(ctypes.Structure):
+    """mi355fft_plan_options (include/mi355fft.h)."""
+    _fields_ = [("struct_size", ctypes.c_size_t), ("algorithm", ctypes.c_int), ("twiddle_fn", TWIDDLE_FN), ("twiddle_ctx", ctypes.c_void_p),
+                ("rader_inner_fft_data", ctypes.c_void_p), ("bluestein_twiddles", ctypes.c_void_p), ("bluestein_multiplier", ctypes.c_void_p),
+                ("bluestein_inner_len", ctypes.c_size_t)]
+
+
 def bind(lib):
     """Attach argtypes/restypes for every symbol include/mi355fft.h declares."""
     vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
     lib.mi355fft_device_count.restype = ci
     lib.mi355fft_init.argtypes = [ci]
     lib.mi355fft_plan_create.argtypes = [sz, ci, ci, ctypes.POINTER(vp)]
+    lib.mi355fft_plan_create_ex.argtypes = [sz, ci, ci, ctypes.POINTER(PlanOptions), ctypes.POINTER(vp)]
+    lib.mi355fft_bluestein_inner_len.restype = sz
+    lib.mi355fft_bluestein_inner_len.argtypes = [sz, ci]
     lib.mi355fft_plan_destroy.argtypes = [vp]
     lib.mi355fft_plan_len.restype = sz
     lib.mi355fft_plan_len.argtypes = [vp]

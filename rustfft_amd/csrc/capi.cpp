@@ -128,28 +128,58 @@ int mi355fft_init(int device) {
     return MI355FFT_OK;
 }
 
-int mi355fft_plan_create(size_t len, int direction, int precision, mi355fft_plan** out_plan) {
+int mi355fft_plan_create_ex(size_t len, int direction, int precision, const mi355fft_plan_options* opts, mi355fft_plan** out_plan) {
     if (!out_plan) return set_err(MI355FFT_ERR_INVALID_ARG, "out_plan is null");
     *out_plan = nullptr;
     if (precision != 32 && precision != 64) return set_err(MI355FFT_ERR_INVALID_ARG, "precision must be 32 or 64");
     if (direction != MI355FFT_FORWARD && direction != MI355FFT_INVERSE) return set_err(MI355FFT_ERR_INVALID_ARG, "bad direction");
+    mi355fft_plan_options o{};
+    if (opts) {
+        if (opts->struct_size < sizeof(size_t) + sizeof(int) || opts->struct_size > sizeof(o))
+            return set_err(MI355FFT_ERR_INVALID_ARG, "mi355fft_plan_options.struct_size does not match this library");
+        memcpy(&o, opts, opts->struct_size);  // fields past the caller's struct_size stay zero (older callers)
+        if (o.algorithm < MI355FFT_ALGO_AUTO || o.algorithm > MI355FFT_ALGO_MIXED_RADIX) return set_err(MI355FFT_ERR_INVALID_ARG, "unknown algorithm");
+        if (o.rader_inner_fft_data && o.algorithm != MI355FFT_ALGO_RADER)
+            return set_err(MI355FFT_ERR_INVALID_ARG, "rader_inner_fft_data needs algorithm = MI355FFT_ALGO_RADER");
+        if ((o.bluestein_twiddles || o.bluestein_multiplier) && o.algorithm != MI355FFT_ALGO_BLUESTEIN)
+            return set_err(MI355FFT_ERR_INVALID_ARG, "Bluestein tables need algorithm = MI355FFT_ALGO_BLUESTEIN");
+    }
     if (int rc = ensure_init()) return rc;
     mi355fft_plan* p = new mi355fft_plan();
     p->p.len = len;
     p->p.direction = direction;
     p->p.prec = precision;
+    p->p.algorithm = o.algorithm;
+    p->p.tw_fn = o.twiddle_fn;
+    p->p.tw_ctx = o.twiddle_ctx;
+    p->p.opt_rader = o.rader_inner_fft_data;
+    p->p.opt_bs_tw = o.bluestein_twiddles;
+    p->p.opt_bs_mul = o.bluestein_multiplier;
+    p->p.opt_bs_inner = o.bluestein_inner_len;
     int rc = build_plan(p->p);
+    // the caller's tables and callback are only borrowed for the duration of this call
+    p->p.tw_fn = nullptr;
+    p->p.tw_ctx = nullptr;
+    p->p.opt_rader = p->p.opt_bs_tw = p->p.opt_bs_mul = nullptr;
     if (rc != MI355FFT_OK) {
         delete p;
         if (rc == MI355FFT_ERR_UNSUPPORTED) {
-            char buf[160];
-            snprintf(buf, sizeof buf, "length %zu (precision %d) has no GPU plan in this build", len, precision);
+            char buf[200];
+            snprintf(buf, sizeof buf, "length %zu (precision %d, algorithm %d) has no GPU plan in this build", len, precision, o.algorithm);
             return set_err(rc, buf);
         }
+        if (rc == MI355FFT_ERR_INVALID_ARG) return set_err(rc, "host tables do not fit the kernels of this length (see mi355fft_bluestein_inner_len)");
         return rc == MI355FFT_ERR_HIP ? hip_err(rc) : set_err(rc, "plan construction failed");
     }
     *out_plan = p;
     return MI355FFT_OK;
+}
+int mi355fft_plan_create(size_t len, int direction, int precision, mi355fft_plan** out_plan) {
+    return mi355fft_plan_create_ex(len, direction, precision, nullptr, out_plan);
+}
+size_t mi355fft_bluestein_inner_len(size_t len, int precision) {
+    if (precision != 32 && precision != 64) return 0;
+    return bluestein_inner_len(len, precision);
 }
 
 int mi355fft_plan_destroy(mi355fft_plan* plan) {

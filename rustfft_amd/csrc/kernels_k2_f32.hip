@@ -8,16 +8,21 @@ void register_k2_f32(std::vector<KernelEntry>& reg) {
     MI_K2(float, 32, 32, false, 256, 16, 16, 16);
     // 512-row tile: 32 columns (256-byte row segments), 32 values per thread, split exchange (measured +12 % at 2^18 over the
     // 16-column full-complex tile, kept as variant 9)
-    MI_K2(float, 32, 32, true, 512, 16, 8, 8, 8);
-    MI_K2V(9, float, 32, 16, false, 512, 32, 16, 8, 4);
+    // (interleaved A/B on one box, round 2: as a FIRST pass the 16-column full-complex tile moves 5.45 TB/s against 5.18, as a
+    // later pass 4.79 against 5.12 -- each kind gets its better tiling)
+    MI_K2_LATER(float, 32, 32, true, 512, 16, 8, 8, 8);
+    MI_K2_FIRST(float, 32, 16, false, 512, 32, 16, 8, 4);
     // 1024-row tile: 16 columns (128-byte row segments), 32 values per thread, real/imaginary planes exchanged
     // one after the other so two workgroups fit a CU's LDS; the twiddled sub-passes are radix 8 (fewer live twiddles)
     MI_K2(float, 32, 16, true, 1024, 32, 8, 8, 16);
     // 2048-row tile (2^21 and 2^22 in two passes instead of three): 16 columns = 128-byte row segments through the split
     // exchange (135 KB of LDS, one 1024-thread workgroup per CU).  Measured at 2^22: 14.0 TFLOP/s against 13.0 for the
     // 8-column tile (64-byte segments, two workgroups per CU, tiles paired per XCD), kept as variant 2.
-    MI_K2(float, 32, 16, true, 2048, 64, 8, 16, 16);
-    MI_K2V(2, float, 32, 8, true, 2048, 64, 8, 16, 16);
+    // Round 2 (XCD-aware tile order in place): as a FIRST pass the 8-column tile (two 512-thread workgroups per CU, contiguous
+    // 128 KiB writes) moves 4.94 - 5.02 TB/s against 4.41 - 4.47 for the 16-column one; as a later pass (64-byte strided
+    // writes) 3.85 against 4.25.
+    MI_K2_FIRST(float, 32, 8, true, 2048, 64, 8, 16, 16);
+    MI_K2_LATER(float, 32, 16, true, 2048, 64, 8, 16, 16);
     MI_K2V(1, float, 32, 8, false, 1024, 64, 16, 16, 4);   // tuning: 64-byte row segments paired per XCD, full-complex exchange
     MI_K2V(3, float, 32, 8, true, 1024, 32, 8, 8, 16);     // tuning: 8-column tiles (paired per XCD), 256 threads, four workgroups per CU
     MI_K2V(10, float, 32, 16, true, 1024, 32, 32, 32);     // tuning: two radix-32 sub-passes, one exchange (the later pass spills)

@@ -507,6 +507,10 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
 #define MI_K2V(V, T, PREC, F, SPLIT, ...) (void)0
 #define MI_K2ABL(V, ABL, T, PREC, F, SPLIT, ...) (void)0
 #endif
+// one pass kind only: the first pass (contiguous writes) and the later passes (strided writes) of one tile height may
+// prefer different tilings
+#define MI_K2_FIRST(T, PREC, F, SPLIT, ...) reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, true, SPLIT>(PREC, "k2first<" #__VA_ARGS__ ">xF" #F))
+#define MI_K2_LATER(T, PREC, F, SPLIT, ...) reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, false, SPLIT>(PREC, "k2later<" #__VA_ARGS__ ">xF" #F))
 #define MI_K2(T, PREC, F, SPLIT, ...)                                                                  \
     reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, true, SPLIT>(PREC, "k2first<" #__VA_ARGS__ ">xF" #F)); \
     reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, false, SPLIT>(PREC, "k2later<" #__VA_ARGS__ ">xF" #F))

@@ -100,8 +100,15 @@ static const KernelEntry* find_kernel(int kind, int prec, size_t n) {
     return fallback;
 }
 
-// src/twiddles.rs:6-23 — forward twiddle, f64 angle, rounded to T by the caller
+// src/twiddles.rs:6-23 — forward twiddle, f64 angle, rounded to T by the caller.  While a plan is being built with
+// mi355fft_plan_options::twiddle_fn set, every entry comes from the host planner's own compute_twiddle instead.
+static thread_local mi355fft_twiddle_fn t_twiddle_fn = nullptr;
+static thread_local void* t_twiddle_ctx = nullptr;
 static inline void twiddle_f64(size_t index, size_t fft_len, double* re, double* im) {
+    if (t_twiddle_fn) {
+        t_twiddle_fn(t_twiddle_ctx, index, fft_len, re, im);
+        return;
+    }
     const double constant = -2.0 * 3.14159265358979323846264338327950288 / (double)fft_len;
     const double angle = constant * (double)index;
     *re = std::cos(angle);
@@ -448,6 +455,22 @@ static bool choose_general_radices(int prec, size_t n, std::vector<size_t>& out)
     return true;
 }
 
+// two-level table for w_Q^e, e < Q:  e = (e >> h) << h | (e & mask)  (the inter-pass twiddles of pass p > 0, Q = S R)
+template <class T> static int build_lohi(Plan& plan, PassDesc& pd, size_t Q) {
+    int rc = MI355FFT_OK, bits = 0;
+    while (((size_t)1 << bits) < Q) ++bits;
+    const int h = (bits + 1) / 2;
+    std::vector<T> lo, hi;
+    for (size_t e = 0; e < ((size_t)1 << h); ++e) push_tw<T>(lo, e, Q);
+    for (size_t q = 0; q <= ((Q - 1) >> h); ++q) push_tw<T>(hi, q << h, Q);
+    pd.hshift = h;
+    pd.lmask = (int)(((size_t)1 << h) - 1);
+    pd.d_tlo = upload<T>(plan, lo, &rc);
+    if (rc) return rc;
+    pd.d_thi = upload<T>(plan, hi, &rc);
+    return rc;
+}
+
 // Passes of one length-N transform over the general column-tile kernels; kinds[p] names the kernel family of pass p
 // (plain first / later, or one of the fused Bluestein passes).
 template <class T>
@@ -468,21 +491,7 @@ static int append_general_passes(Plan& plan, size_t N, const std::vector<size_t>
         pd.d_aux1 = (p == 0) ? tab_first : (p + 1 == radices.size()) ? tab_last : nullptr;
         pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(*k), &rc);
         if (rc) return rc;
-        if (p > 0) {
-            const size_t Q = s * R;
-            int bits = 0;
-            while (((size_t)1 << bits) < Q) ++bits;
-            const int h = (bits + 1) / 2;
-            std::vector<T> lo, hi;
-            for (size_t e = 0; e < ((size_t)1 << h); ++e) push_tw<T>(lo, e, Q);
-            for (size_t q = 0; q <= ((Q - 1) >> h); ++q) push_tw<T>(hi, q << h, Q);
-            pd.hshift = h;
-            pd.lmask = (int)(((size_t)1 << h) - 1);
-            pd.d_tlo = upload<T>(plan, lo, &rc);
-            if (rc) return rc;
-            pd.d_thi = upload<T>(plan, hi, &rc);
-            if (rc) return rc;
-        }
+        if (p > 0 && (rc = build_lohi<T>(plan, pd, s * R))) return rc;
         plan.passes.push_back(pd);
         s *= R;
     }
@@ -531,6 +540,146 @@ static bool choose_fused_radices(int prec, size_t need, std::vector<size_t>& out
     return false;
 }
 
+// host table handed over by the caller's planner (interleaved Complex<T>, in the PLAN's direction) -> forward-direction
+// complex doubles: the device runs the inverse as conj(FFT(conj x)), and every table of the reference's inverse
+// algorithm objects is the conjugate of the forward one
+template <class T> static std::vector<cd> from_host_table(const void* p, size_t n, bool inverse) {
+    const T* t = (const T*)p;
+    std::vector<cd> v(n);
+    for (size_t i = 0; i < n; ++i) v[i] = cd((double)t[2 * i], inverse ? -(double)t[2 * i + 1] : (double)t[2 * i + 1]);
+    return v;
+}
+
+// Rader tables (raders_algorithm.rs:65-124): d[j] = FFT_{p-1}(twiddle(g^-j mod p, p)) / (p - 1), g^(j+1), g^-(j+1)
+template <class T> static int rader_tables(Plan& plan, PassDesc& pd, bool inverse_map_in) {
+    const uint64_t pp = plan.len, g = primitive_root(pp), ginv = modpow(g, pp - 2, pp);
+    std::vector<cd> d(pp - 1);
+    std::vector<int> pin(pp - 1), pout(pp - 1);
+    uint64_t ti = 1, a = 1, b = 1;
+    for (size_t j = 0; j + 1 < pp; ++j) {
+        double re, im;
+        twiddle_f64(ti, pp, &re, &im);
+        d[j] = cd(re, im) / (double)(pp - 1);
+        ti = ti * ginv % pp;
+        a = a * g % pp;
+        b = b * ginv % pp;
+        pin[j] = (int)a;
+        pout[j] = (int)b;
+    }
+    if (plan.opt_rader)
+        d = from_host_table<T>(plan.opt_rader, pp - 1, plan.direction == MI355FFT_INVERSE);
+    else
+        host_dft(d);
+    if (inverse_map_in) {  // bodies that scatter on load want the inverse map t -> j with g^(j+1) = t
+        std::vector<int> inv(pp, 0);
+        for (size_t j = 0; j + 1 < pp; ++j) inv[(size_t)pin[j]] = (int)j;
+        pin.swap(inv);
+    }
+    int rc = MI355FFT_OK;
+    pd.d_aux1 = upload<T>(plan, to_interleaved<T>(d), &rc);
+    if (rc) return rc;
+    pd.d_perm_in = upload<int>(plan, pin, &rc);
+    if (rc) return rc;
+    pd.d_perm_out = upload<int>(plan, pout, &rc);
+    return rc;
+}
+
+// Bluestein tables (bluesteins_algorithm.rs:63-98): chirp[n], and FFT_M of the mirrored conjugate chirp scaled by 1 / M
+template <class T> static int bluestein_tables(Plan& plan, size_t M, void** d_chirp, void** d_bf) {
+    const size_t n = plan.len;
+    const bool inverse = plan.direction == MI355FFT_INVERSE;
+    if (plan.opt_bs_mul && plan.opt_bs_inner != M) return MI355FFT_ERR_INVALID_ARG;  // sized for another inner length
+    std::vector<cd> chirp = plan.opt_bs_tw ? from_host_table<T>(plan.opt_bs_tw, n, inverse) : bluestein_chirp(n);
+    std::vector<cd> bvec;
+    if (plan.opt_bs_mul) {
+        bvec = from_host_table<T>(plan.opt_bs_mul, M, inverse);
+    } else {
+        bvec.assign(M, cd(0, 0));
+        bvec[0] = std::conj(chirp[0]) / (double)M;
+        for (size_t i = 1; i < n; ++i) {
+            bvec[i] = std::conj(chirp[i]) / (double)M;
+            bvec[M - i] = bvec[i];
+        }
+        host_dft(bvec);
+    }
+    int rc = MI355FFT_OK;
+    *d_chirp = upload<T>(plan, to_interleaved<T>(chirp), &rc);
+    if (rc) return rc;
+    *d_bf = upload<T>(plan, to_interleaved<T>(bvec), &rc);
+    return rc;
+}
+
+// Which Bluestein form serves length n, and over which inner length M (shared by the planner and
+// mi355fft_bluestein_inner_len).  form: 1 = one kernel, 2 = two whole-row kernels, 3 = fused column-tile passes,
+// 4 = separate element-wise kernels around an inner plan; 0 = none.
+struct BluesteinChoice {
+    int form = 0;
+    size_t M = 0;
+    const KernelEntry* k1 = nullptr;
+    const KernelEntry* k2 = nullptr;
+    std::vector<size_t> radices;
+};
+static BluesteinChoice choose_bluestein(int prec, size_t n) {
+    BluesteinChoice c;
+    if (n < 2) return c;
+    for (auto& e : registry())
+        if (e.kind == KIND_BLUESTEIN && e.prec == prec && e.variant == 0 && (size_t)e.n >= 2 * n - 1 && (!c.k1 || e.n < c.k1->n)) c.k1 = &e;
+    if (c.k1 && env_int("MI355FFT_VARIANT"))  // tuning: an alternative body for the same inner length
+        for (auto& e : registry())
+            if (e.kind == KIND_BLUESTEIN && e.prec == prec && e.n == c.k1->n && e.variant == env_int("MI355FFT_VARIANT")) c.k1 = &e;
+    if (c.k1) {
+        c.form = 1;
+        c.M = c.k1->n;
+        return c;
+    }
+    if (env_int("MI355FFT_BLUESTEIN_UNFUSED") == 0) {
+        for (auto& e : registry())
+            if (e.kind == KIND_BS2_FIRST && e.prec == prec && e.variant == 0 && (size_t)e.n >= 2 * n - 1 && (!c.k1 || e.n < c.k1->n) &&
+                find_kernel(KIND_BS2_SECOND, prec, e.n))
+                c.k1 = &e;
+        if (c.k1) {
+            c.form = 2;
+            c.M = c.k1->n;
+            c.k2 = find_kernel(KIND_BS2_SECOND, prec, c.k1->n);
+            return c;
+        }
+        if (2 * n - 1 < ((size_t)1 << 31) && choose_fused_radices(prec, 2 * n - 1, c.radices)) {
+            c.form = 3;
+            c.M = 1;
+            for (size_t r : c.radices) c.M *= r;
+            return c;
+        }
+    }
+    size_t M = 1;
+    while (M < 2 * n - 1) M <<= 1;
+    // a 7-smooth M between 2n - 1 and that power of two pads less (every pass of the pipeline runs over M, not n):
+    // take the smallest one the general passes cover in no more kernels than the power of two needs
+    if (M < ((size_t)1 << 31) && env_int("MI355FFT_BLUESTEIN_POW2") == 0) {
+        std::vector<size_t> r0, r1, cand;
+        const size_t p0 = choose_macro_radices(prec, M, r0) ? r0.size() : 4;
+        for (size_t a = 1; a < M; a *= 2)
+            for (size_t b = a; b < M; b *= 3)
+                for (size_t cc = b; cc < M; cc *= 5)
+                    for (size_t d = cc; d < M; d *= 7)
+                        if (d >= 2 * n - 1 && d > 4096) cand.push_back(d);
+        std::sort(cand.begin(), cand.end());
+        for (size_t cnd : cand)
+            if (cnd * 20 <= M * 17 && choose_general_radices(prec, cnd, r1) && r1.size() <= p0) {  // >= 15 % smaller: the general passes run ~10 % below the power-of-two tiles
+                M = cnd;
+                break;
+            }
+    }
+    if (M < ((size_t)1 << 31)) {
+        c.form = 4;
+        c.M = M;
+    }
+    return c;
+}
+size_t bluestein_inner_len(size_t len, int prec) {
+    ensure_registry();
+    return choose_bluestein(prec, len).M;
+}
+
 template <class T> static int build_plan_t(Plan& plan) {
     const size_t n = plan.len;
     if (n <= 1) {
@@ -538,132 +687,77 @@ template <class T> static int build_plan_t(Plan& plan) {
         return MI355FFT_OK;
     }
     int rc = MI355FFT_OK;
-    if (const KernelEntry* k = find_kernel(KIND_K1, plan.prec, n)) {
-        if (k->prepare()) return MI355FFT_ERR_HIP;
-        plan.kind = PLAN_SINGLE;
-        PassDesc pd{};
-        pd.k = k;
-        pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(*k), &rc);
-        if (rc) return rc;
-        plan.passes.push_back(pd);
-        return MI355FFT_OK;
-    }
+    const int algo = plan.algorithm;
+    const bool direct_ok = (algo == MI355FFT_ALGO_AUTO || algo == MI355FFT_ALGO_MIXED_RADIX);
+    const bool rader_ok = (algo == MI355FFT_ALGO_AUTO || algo == MI355FFT_ALGO_RADER);
+    const bool bluestein_ok = (algo == MI355FFT_ALGO_AUTO || algo == MI355FFT_ALGO_BLUESTEIN);
+    if (algo == MI355FFT_ALGO_RADER && (!is_prime_sz(n) || n < 5)) return MI355FFT_ERR_UNSUPPORTED;  // raders_algorithm.rs:68
     std::vector<size_t> radices;
-    // the large-N passes address one transform with 32-bit element offsets
-    if (n < ((size_t)1 << 31) && choose_macro_radices(plan.prec, n, radices)) {
-        plan.kind = PLAN_MACRO;
-        size_t s = 1;
-        for (size_t p = 0; p < radices.size(); ++p) {
-            const size_t R = radices[p];
-            const KernelEntry* k = find_kernel(p == 0 ? KIND_K2_FIRST : KIND_K2_LATER, plan.prec, R);
+    if (direct_ok) {
+        if (const KernelEntry* k = find_kernel(KIND_K1, plan.prec, n)) {
             if (k->prepare()) return MI355FFT_ERR_HIP;
-            const size_t M = n / R;
-            if (M % k->f != 0 || (p > 0 && s % k->f != 0)) return MI355FFT_ERR_UNSUPPORTED;
+            plan.kind = PLAN_SINGLE;
             PassDesc pd{};
             pd.k = k;
-            pd.m = (long long)M;
-            pd.s = (long long)s;
             pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(*k), &rc);
             if (rc) return rc;
-            if (p > 0) {
-                // two-level table for w_Q^e, Q = S R, e < Q:  e = (e >> h) << h | (e & mask)
-                const size_t Q = s * R;
-                int bits = 0;
-                while (((size_t)1 << bits) < Q) ++bits;
-                const int h = (bits + 1) / 2;
-                std::vector<T> lo, hi;
-                for (size_t e = 0; e < ((size_t)1 << h); ++e) push_tw<T>(lo, e, Q);
-                for (size_t q = 0; q <= ((Q - 1) >> h); ++q) push_tw<T>(hi, q << h, Q);
-                pd.hshift = h;
-                pd.lmask = (int)(((size_t)1 << h) - 1);
-                pd.d_tlo = upload<T>(plan, lo, &rc);
-                if (rc) return rc;
-                pd.d_thi = upload<T>(plan, hi, &rc);
-                if (rc) return rc;
-            }
             plan.passes.push_back(pd);
-            s *= R;
+            return MI355FFT_OK;
         }
-        return MI355FFT_OK;
-    }
-    // composite lengths above one workgroup whose factors are 2, 3, 5, 7: two to four general passes (k2g_body)
-    if (n > 4096 && n < ((size_t)1 << 31) && choose_general_radices(plan.prec, n, radices)) {
-        plan.kind = PLAN_MACRO;
-        size_t s = 1;
-        for (size_t p = 0; p < radices.size(); ++p) {
-            const size_t R = radices[p];
-            const KernelEntry* k = find_kernel(p == 0 ? KIND_K2G_FIRST : KIND_K2G_LATER, plan.prec, R);
-            if (k->prepare()) return MI355FFT_ERR_HIP;
-            PassDesc pd{};
-            pd.k = k;
-            pd.m = (long long)(n / R);
-            pd.s = (long long)s;
-            pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(*k), &rc);
+        // the large-N passes address one transform with 32-bit element offsets
+        if (n < ((size_t)1 << 31) && choose_macro_radices(plan.prec, n, radices)) {
+            plan.kind = PLAN_MACRO;
+            size_t s = 1;
+            for (size_t p = 0; p < radices.size(); ++p) {
+                const size_t R = radices[p];
+                const KernelEntry* k = find_kernel(p == 0 ? KIND_K2_FIRST : KIND_K2_LATER, plan.prec, R);
+                if (k->prepare()) return MI355FFT_ERR_HIP;
+                const size_t M = n / R;
+                if (M % k->f != 0 || (p > 0 && s % k->f != 0)) return MI355FFT_ERR_UNSUPPORTED;
+                PassDesc pd{};
+                pd.k = k;
+                pd.m = (long long)M;
+                pd.s = (long long)s;
+                pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(*k), &rc);
+                if (rc) return rc;
+                if (p > 0 && (rc = build_lohi<T>(plan, pd, s * R))) return rc;
+                plan.passes.push_back(pd);
+                s *= R;
+            }
+            return MI355FFT_OK;
+        }
+        // composite lengths above one workgroup whose factors are 2, 3, 5, 7: two to four general passes (k2g_body)
+        if (n > 4096 && n < ((size_t)1 << 31) && choose_general_radices(plan.prec, n, radices)) {
+            plan.kind = PLAN_MACRO;
+            std::vector<int> kinds(radices.size(), KIND_K2G_LATER);
+            kinds[0] = KIND_K2G_FIRST;
+            rc = append_general_passes<T>(plan, n, radices, kinds, nullptr, nullptr);
             if (rc) return rc;
-            if (p > 0) {
-                const size_t Q = s * R;
-                int bits = 0;
-                while (((size_t)1 << bits) < Q) ++bits;
-                const int h = (bits + 1) / 2;
-                std::vector<T> lo, hi;
-                for (size_t e = 0; e < ((size_t)1 << h); ++e) push_tw<T>(lo, e, Q);
-                for (size_t q = 0; q <= ((Q - 1) >> h); ++q) push_tw<T>(hi, q << h, Q);
-                pd.hshift = h;
-                pd.lmask = (int)(((size_t)1 << h) - 1);
-                pd.d_tlo = upload<T>(plan, lo, &rc);
-                if (rc) return rc;
-                pd.d_thi = upload<T>(plan, hi, &rc);
-                if (rc) return rc;
-            }
-            plan.passes.push_back(pd);
-            s *= R;
+            for (auto& pd : plan.passes) pd.row_n = 0;
+            return MI355FFT_OK;
         }
-        return MI355FFT_OK;
     }
     // prime length with a compiled Rader body (raders_algorithm.rs:65-124 precomputation, in f64)
-    for (auto& e0 : registry()) {
-        if (e0.kind != KIND_RADER || e0.prec != plan.prec || (size_t)e0.aux != n || e0.variant != 0) continue;
-        const KernelEntry* chosen = &e0;
-        for (auto& ev : registry())  // tuning: MI355FFT_VARIANT selects an alternative tiling of the same prime
-            if (ev.kind == KIND_RADER && ev.prec == plan.prec && ev.aux == e0.aux && ev.variant == env_int("MI355FFT_VARIANT")) chosen = &ev;
-        const KernelEntry& e = *chosen;
-        if (e.prepare()) return MI355FFT_ERR_HIP;
-        const uint64_t pp = n, g = primitive_root(pp), ginv = modpow(g, pp - 2, pp);
-        std::vector<cd> d(pp - 1);
-        std::vector<int> pin(pp - 1), pout(pp - 1);
-        uint64_t ti = 1, a = 1, b = 1;
-        for (size_t j = 0; j + 1 < pp; ++j) {
-            double re, im;
-            twiddle_f64(ti, pp, &re, &im);
-            d[j] = cd(re, im) / (double)(pp - 1);
-            ti = ti * ginv % pp;
-            a = a * g % pp;
-            b = b * ginv % pp;
-            pin[j] = (int)a;
-            pout[j] = (int)b;
+    if (rader_ok) {
+        for (auto& e0 : registry()) {
+            if (e0.kind != KIND_RADER || e0.prec != plan.prec || (size_t)e0.aux != n || e0.variant != 0) continue;
+            const KernelEntry* chosen = &e0;
+            for (auto& ev : registry())  // tuning: MI355FFT_VARIANT selects an alternative tiling of the same prime
+                if (ev.kind == KIND_RADER && ev.prec == plan.prec && ev.aux == e0.aux && ev.variant == env_int("MI355FFT_VARIANT")) chosen = &ev;
+            const KernelEntry& e = *chosen;
+            if (e.prepare()) return MI355FFT_ERR_HIP;
+            plan.kind = PLAN_RADER;
+            PassDesc pd{};
+            pd.k = &e;
+            pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(e), &rc);
+            if (rc) return rc;
+            if ((rc = rader_tables<T>(plan, pd, e.split))) return rc;  // e.split: MODE >= 1 bodies scatter on load
+            plan.passes.push_back(pd);
+            return MI355FFT_OK;
         }
-        host_dft(d);
-        if (e.split) {  // MODE 1 bodies scatter on load: they want the inverse map t -> j with g^(j+1) = t
-            std::vector<int> inv(pp, 0);
-            for (size_t j = 0; j + 1 < pp; ++j) inv[(size_t)pin[j]] = (int)j;
-            pin.swap(inv);
-        }
-        plan.kind = PLAN_RADER;
-        PassDesc pd{};
-        pd.k = &e;
-        pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(e), &rc);
-        if (rc) return rc;
-        pd.d_aux1 = upload<T>(plan, to_interleaved<T>(d), &rc);
-        if (rc) return rc;
-        pd.d_perm_in = upload<int>(plan, pin, &rc);
-        if (rc) return rc;
-        pd.d_perm_out = upload<int>(plan, pout, &rc);
-        if (rc) return rc;
-        plan.passes.push_back(pd);
-        return MI355FFT_OK;
     }
     // 13-smooth lengths that fit one workgroup: the run-time scheduled mixed-radix kernel (the RadixN analogue)
-    if (env_int("MI355FFT_NO_DYN") == 0) {
+    if (direct_ok && env_int("MI355FFT_NO_DYN") == 0) {
         DynSched ds;
         const KernelEntry* dk = find_kind(KIND_DYN_K1, plan.prec);
         if (dk && build_dyn_sched(n, 2 * sizeof(T), 0, ds)) {
@@ -677,183 +771,91 @@ template <class T> static int build_plan_t(Plan& plan) {
             plan.passes.push_back(pd);
             return MI355FFT_OK;
         }
-        // primes whose p - 1 is 13-smooth: run-time scheduled Rader (raders_algorithm.rs:65-124 tables in f64)
+    }
+    // primes whose p - 1 is 13-smooth and that have no compiled body: run-time scheduled Rader.  Measured slower than the
+    // one-workgroup Bluestein on MI355X, so AUTO does not pick it; a host planner asks for it with MI355FFT_ALGO_RADER.
+    if (algo == MI355FFT_ALGO_RADER) {
+        DynSched ds;
         const KernelEntry* rk = find_kind(KIND_DYN_RADER, plan.prec);
-        // (measured slower than the one-workgroup Bluestein on MI355X, so it is opt-in: MI355FFT_DYN_RADER=1)
-        if (rk && env_int("MI355FFT_DYN_RADER") && is_prime_sz(n) && n > 3 && build_dyn_sched(n - 1, 2 * sizeof(T), n, ds)) {
+        if (rk && build_dyn_sched(n - 1, 2 * sizeof(T), n, ds)) {
             if (rk->prepare()) return MI355FFT_ERR_HIP;
-            const uint64_t pp = n, g = primitive_root(pp), ginv = modpow(g, pp - 2, pp);
-            std::vector<cd> d(pp - 1);
-            std::vector<int> pin(pp - 1), pout(pp - 1);
-            uint64_t ti = 1, a = 1, b = 1;
-            for (size_t j = 0; j + 1 < pp; ++j) {
-                double re, im;
-                twiddle_f64(ti, pp, &re, &im);
-                d[j] = cd(re, im) / (double)(pp - 1);
-                ti = ti * ginv % pp;
-                a = a * g % pp;
-                b = b * ginv % pp;
-                pin[j] = (int)a;
-                pout[j] = (int)b;
-            }
-            host_dft(d);
             plan.kind = PLAN_RADER;
             PassDesc pd{};
             pd.k = rk;
             pd.dyn = ds;
             pd.d_tw = upload<T>(plan, build_dyn_twiddles<T>(ds), &rc);
             if (rc) return rc;
-            pd.d_aux1 = upload<T>(plan, to_interleaved<T>(d), &rc);
-            if (rc) return rc;
-            pd.d_perm_in = upload<int>(plan, pin, &rc);
-            if (rc) return rc;
-            pd.d_perm_out = upload<int>(plan, pout, &rc);
-            if (rc) return rc;
+            if ((rc = rader_tables<T>(plan, pd, false))) return rc;
             plan.passes.push_back(pd);
             return MI355FFT_OK;
         }
+        return MI355FFT_ERR_UNSUPPORTED;
     }
-    // any other length that fits one workgroup: Bluestein over the smallest compiled M >= 2n - 1
-    {
-        const KernelEntry* best = nullptr;
-        for (auto& e : registry())
-            if (e.kind == KIND_BLUESTEIN && e.prec == plan.prec && e.variant == 0 && (size_t)e.n >= 2 * n - 1 && (!best || e.n < best->n)) best = &e;
-        if (best && env_int("MI355FFT_VARIANT"))  // tuning: an alternative body for the same inner length
-            for (auto& e : registry())
-                if (e.kind == KIND_BLUESTEIN && e.prec == plan.prec && e.n == best->n && e.variant == env_int("MI355FFT_VARIANT")) best = &e;
-        if (best) {
-            if (best->prepare()) return MI355FFT_ERR_HIP;
-            const size_t M = best->n;
-            std::vector<cd> chirp = bluestein_chirp(n), bvec(M, cd(0, 0));
-            // bluesteins_algorithm.rs:63-87: mirrored conjugate chirp scaled by 1/M, then the forward FFT_M
-            bvec[0] = std::conj(chirp[0]) / (double)M;
-            for (size_t i = 1; i < n; ++i) {
-                bvec[i] = std::conj(chirp[i]) / (double)M;
-                bvec[M - i] = bvec[i];
-            }
-            host_dft(bvec);
-            plan.kind = PLAN_BLUESTEIN;
-            PassDesc pd{};
-            pd.k = best;
-            pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(*best), &rc);
-            if (rc) return rc;
-            pd.d_aux1 = upload<T>(plan, to_interleaved<T>(chirp), &rc);
-            if (rc) return rc;
-            pd.d_aux2 = upload<T>(plan, to_interleaved<T>(bvec), &rc);
-            if (rc) return rc;
-            plan.passes.push_back(pd);
-            return MI355FFT_OK;
-        }
-    }
-    // 4096 < n with 2n - 1 <= 32768 (f64: 16384): two-kernel Bluestein, each kernel one whole-row transform of the padded
-    // length through the split exchange (k1bs_body)
-    if (env_int("MI355FFT_BLUESTEIN_UNFUSED") == 0) {
-        const KernelEntry* best = nullptr;
-        for (auto& e : registry())
-            if (e.kind == KIND_BS2_FIRST && e.prec == plan.prec && e.variant == 0 && (size_t)e.n >= 2 * n - 1 && (!best || e.n < best->n) &&
-                find_kernel(KIND_BS2_SECOND, plan.prec, e.n))
-                best = &e;
-        if (best) {
-            const KernelEntry* second = find_kernel(KIND_BS2_SECOND, plan.prec, best->n);
-            if (best->prepare() || second->prepare()) return MI355FFT_ERR_HIP;
-            const size_t M = best->n;
-            std::vector<cd> chirp = bluestein_chirp(n), bvec(M, cd(0, 0));
-            bvec[0] = std::conj(chirp[0]) / (double)M;
-            for (size_t i = 1; i < n; ++i) {
-                bvec[i] = std::conj(chirp[i]) / (double)M;
-                bvec[M - i] = bvec[i];
-            }
-            host_dft(bvec);
-            PassDesc pd{};
-            pd.k = best;
-            pd.row_n = (long long)M;
-            pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(*best), &rc);
-            if (rc) return rc;
-            pd.d_aux1 = upload<T>(plan, to_interleaved<T>(chirp), &rc);
-            if (rc) return rc;
-            pd.d_aux2 = upload<T>(plan, to_interleaved<T>(bvec), &rc);
-            if (rc) return rc;
-            plan.passes.push_back(pd);
-            pd.k = second;
-            plan.passes.push_back(pd);
-            plan.kind = PLAN_BLUESTEIN_2K;
-            return MI355FFT_OK;
-        }
-    }
-    // any other length: multi-kernel Bluestein (bluesteins_algorithm.rs:58-136) with the inner FFT_M realised by the
-    // general column-tile passes and the three element-wise stages fused into their first load / last store
-    if (env_int("MI355FFT_BLUESTEIN_UNFUSED") == 0 && 2 * n - 1 < ((size_t)1 << 31) && choose_fused_radices(plan.prec, 2 * n - 1, radices)) {
-        size_t M = 1;
-        for (size_t r : radices) M *= r;
-        std::vector<cd> chirp = bluestein_chirp(n), bvec(M, cd(0, 0));
-        bvec[0] = std::conj(chirp[0]) / (double)M;
-        for (size_t i = 1; i < n; ++i) {
-            bvec[i] = std::conj(chirp[i]) / (double)M;
-            bvec[M - i] = bvec[i];
-        }
-        host_dft(bvec);
-        void* d_chirp = upload<T>(plan, to_interleaved<T>(chirp), &rc);
+    if (!bluestein_ok) return MI355FFT_ERR_UNSUPPORTED;
+    const BluesteinChoice bc = choose_bluestein(plan.prec, n);
+    if (bc.form == 1) {
+        // any length that fits one workgroup: Bluestein over the smallest compiled M >= 2n - 1
+        if (bc.k1->prepare()) return MI355FFT_ERR_HIP;
+        plan.kind = PLAN_BLUESTEIN;
+        PassDesc pd{};
+        pd.k = bc.k1;
+        pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(*bc.k1), &rc);
         if (rc) return rc;
-        void* d_bf = upload<T>(plan, to_interleaved<T>(bvec), &rc);
+        if ((rc = bluestein_tables<T>(plan, bc.M, &pd.d_aux1, &pd.d_aux2))) return rc;
+        plan.passes.push_back(pd);
+        return MI355FFT_OK;
+    }
+    if (bc.form == 2) {
+        // 4096 < n with 2n - 1 <= 32768 (f64: 16384): two-kernel Bluestein, each kernel one whole-row transform of the
+        // padded length through the split exchange (k1bs_body)
+        if (bc.k1->prepare() || bc.k2->prepare()) return MI355FFT_ERR_HIP;
+        PassDesc pd{};
+        pd.k = bc.k1;
+        pd.row_n = (long long)bc.M;
+        pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(*bc.k1), &rc);
         if (rc) return rc;
-        const size_t P = radices.size();
+        if ((rc = bluestein_tables<T>(plan, bc.M, &pd.d_aux1, &pd.d_aux2))) return rc;
+        plan.passes.push_back(pd);
+        pd.k = bc.k2;
+        plan.passes.push_back(pd);
+        plan.kind = PLAN_BLUESTEIN_2K;
+        return MI355FFT_OK;
+    }
+    if (bc.form == 3) {
+        // multi-kernel Bluestein (bluesteins_algorithm.rs:58-136) with the inner FFT_M realised by the general column-tile
+        // passes and the three element-wise stages fused into their first load / last store
+        void *d_chirp = nullptr, *d_bf = nullptr;
+        if ((rc = bluestein_tables<T>(plan, bc.M, &d_chirp, &d_bf))) return rc;
+        const size_t P = bc.radices.size();
         std::vector<int> k1(P, KIND_K2G_LATER), k2(P, KIND_K2G_LATER);
         k1[0] = KIND_K2G_FIRST_CHIRP;
         k1[P - 1] = KIND_K2G_LAST_MUL;
         k2[0] = KIND_K2G_FIRST;
         k2[P - 1] = KIND_K2G_LAST_CHIRP;
-        rc = append_general_passes<T>(plan, M, radices, k1, d_chirp, d_bf);
+        rc = append_general_passes<T>(plan, bc.M, bc.radices, k1, d_chirp, d_bf);
         if (rc) return rc;
-        rc = append_general_passes<T>(plan, M, radices, k2, nullptr, d_chirp);
+        rc = append_general_passes<T>(plan, bc.M, bc.radices, k2, nullptr, d_chirp);
         if (rc) return rc;
         plan.kind = PLAN_BLUESTEIN_FUSED;
         return MI355FFT_OK;
     }
-    // fallback (and MI355FFT_BLUESTEIN_UNFUSED=1): separate chirp / multiply kernels around an inner plan of length M >= 2n - 1
-    {
-        size_t M = 1;
-        while (M < 2 * n - 1) M <<= 1;
-        // a 7-smooth M between 2n - 1 and that power of two pads less (every pass of the pipeline runs over M, not n):
-        // take the smallest one the general passes cover in no more kernels than the power of two needs
-        if (M < ((size_t)1 << 31) && env_int("MI355FFT_BLUESTEIN_POW2") == 0) {
-            std::vector<size_t> r0, r1, cand;
-            const size_t p0 = choose_macro_radices(plan.prec, M, r0) ? r0.size() : 4;
-            for (size_t a = 1; a < M; a *= 2)
-                for (size_t b = a; b < M; b *= 3)
-                    for (size_t c = b; c < M; c *= 5)
-                        for (size_t d = c; d < M; d *= 7)
-                            if (d >= 2 * n - 1 && d > 4096) cand.push_back(d);
-            std::sort(cand.begin(), cand.end());
-            for (size_t c : cand)
-                if (c * 20 <= M * 17 && choose_general_radices(plan.prec, c, r1) && r1.size() <= p0) {  // >= 15 % smaller: the general passes run ~10 % below the power-of-two tiles
-                    M = c;
-                    break;
-                }
-        }
+    if (bc.form == 4) {
+        // fallback (and MI355FFT_BLUESTEIN_UNFUSED=1 in tuning builds): separate chirp / multiply kernels around an inner plan
         const KernelEntry* pw = nullptr;
         for (auto& e : registry())
             if (e.kind == KIND_POINTWISE && e.prec == plan.prec) pw = &e;
-        if (pw && M < ((size_t)1 << 31)) {
+        if (pw) {
             plan.inner.reset(new Plan());
-            plan.inner->len = M;
+            plan.inner->len = bc.M;
             plan.inner->direction = MI355FFT_FORWARD;
             plan.inner->prec = plan.prec;
+            plan.inner->device = plan.device;
             int irc = build_plan_t<T>(*plan.inner);
             if (irc) return irc;
-            std::vector<cd> chirp = bluestein_chirp(n), bvec(M, cd(0, 0));
-            bvec[0] = std::conj(chirp[0]) / (double)M;
-            for (size_t i = 1; i < n; ++i) {
-                bvec[i] = std::conj(chirp[i]) / (double)M;
-                bvec[M - i] = bvec[i];
-            }
-            host_dft(bvec);
             plan.kind = PLAN_BLUESTEIN_LARGE;
             PassDesc pd{};
             pd.k = pw;
-            pd.d_aux1 = upload<T>(plan, to_interleaved<T>(chirp), &rc);
-            if (rc) return rc;
-            pd.d_aux2 = upload<T>(plan, to_interleaved<T>(bvec), &rc);
-            if (rc) return rc;
+            if ((rc = bluestein_tables<T>(plan, bc.M, &pd.d_aux1, &pd.d_aux2))) return rc;
             plan.passes.push_back(pd);
             return MI355FFT_OK;
         }
@@ -864,7 +866,17 @@ template <class T> static int build_plan_t(Plan& plan) {
 int build_plan(Plan& plan) {
     ensure_registry();
     plan.device = backend::current_device();
-    plan.dbg = env_int("MI355FFT_DBG");  // measurement knobs, read once per plan (0 in production)
+    plan.dbg = env_int("MI355FFT_DBG");  // measurement knobs (tuning builds only; 0 in the shipped library)
+    struct TwiddleScope {  // the host planner's compute_twiddle, for this thread, for the duration of the build
+        TwiddleScope(mi355fft_twiddle_fn f, void* c) {
+            t_twiddle_fn = f;
+            t_twiddle_ctx = c;
+        }
+        ~TwiddleScope() {
+            t_twiddle_fn = nullptr;
+            t_twiddle_ctx = nullptr;
+        }
+    } scope(plan.tw_fn, plan.tw_ctx);
     return plan.prec == 32 ? build_plan_t<float>(plan) : build_plan_t<double>(plan);
 }
 

@@ -60,6 +60,14 @@ struct Plan {
     std::vector<void*> device_allocs;
     size_t chunk_batch = 0;
     int dbg = 0;
+    // mi355fft_plan_options (host planner in charge): algorithm family, twiddle source, finished tables
+    int algorithm = 0;
+    mi355fft_twiddle_fn tw_fn = nullptr;
+    void* tw_ctx = nullptr;
+    const void* opt_rader = nullptr;
+    const void* opt_bs_tw = nullptr;
+    const void* opt_bs_mul = nullptr;
+    size_t opt_bs_inner = 0;
     int device = -1;  // HIP device the tables live on (the device current at creation)
     std::mutex ws_mutex;
     std::map<void*, std::unique_ptr<StreamSlot>> slots;  // one execution slot (HBM workspace) per stream
@@ -78,6 +86,7 @@ struct Plan {
 };
 
 int build_plan(Plan& plan);
+size_t bluestein_inner_len(size_t len, int prec);
 int execute(Plan& plan, const void* in, void* out, size_t batch, void* stream, int mode, Tracer* tr);
 
 }  // namespace mi355

@@ -18,6 +18,7 @@ import numpy as np
 from . import _native
 
 SCRATCH_INPLACE, SCRATCH_OUTOFPLACE, SCRATCH_IMMUTABLE = 0, 1, 2
+ALGO_AUTO, ALGO_RADER, ALGO_BLUESTEIN, ALGO_MIXED_RADIX = 0, 1, 2, 3  # top-level Recipe family (src/plan.rs:134-188)
 
 
 class FftDirection(enum.IntEnum):  # src/lib.rs:146-171
@@ -235,6 +236,41 @@ class FftPlannerHip:
                 raise FftPanic(rc, self._lib.mi355fft_last_error().decode() or self._lib.mi355fft_strerror(rc).decode())
             self._cache[key] = Fft(self._lib, h, self.dtype)
         return self._cache[key]
+
+    def plan_fft_with(self, len, direction, algorithm=ALGO_AUTO, twiddle_fn=None, rader_inner_fft_data=None,
+                      bluestein_twiddles=None, bluestein_multiplier=None):
+        """mi355fft_plan_create_ex: the HOST planner in charge -- it names the Recipe family and may supply its own
+        `compute_twiddle(index, fft_len) -> complex` (src/twiddles.rs:6-23, forward direction) and / or its finished Rader /
+        Bluestein tables (numpy arrays of the plan's complex dtype, in the plan's direction).  Not cached."""
+        direction = FftDirection(direction)
+        o = _native.PlanOptions()
+        o.struct_size = ctypes.sizeof(_native.PlanOptions)
+        o.algorithm = int(algorithm)
+        keep = []
+        if twiddle_fn is not None:
+            def thunk(_ctx, index, fft_len, re, im):
+                w = complex(twiddle_fn(index, fft_len))
+                re[0], im[0] = w.real, w.imag
+
+            cb = _native.TWIDDLE_FN(thunk)
+            keep.append(cb)
+            o.twiddle_fn = cb
+        for name, arr in (("rader_inner_fft_data", rader_inner_fft_data), ("bluestein_twiddles", bluestein_twiddles),
+                          ("bluestein_multiplier", bluestein_multiplier)):
+            if arr is not None:
+                a = np.ascontiguousarray(arr, dtype=self.dtype)
+                keep.append(a)
+                setattr(o, name, a.ctypes.data)
+                if name == "bluestein_multiplier":
+                    o.bluestein_inner_len = a.size
+        h = ctypes.c_void_p()
+        rc = self._lib.mi355fft_plan_create_ex(int(len), int(direction), self._prec, ctypes.byref(o), ctypes.byref(h))
+        if rc != 0:
+            raise FftPanic(rc, self._lib.mi355fft_last_error().decode() or self._lib.mi355fft_strerror(rc).decode())
+        return Fft(self._lib, h, self.dtype)
+
+    def bluestein_inner_len(self, len):
+        return int(self._lib.mi355fft_bluestein_inner_len(int(len), self._prec))
 
     def plan_fft_forward(self, len):
         return self.plan_fft(len, FftDirection.Forward)

@@ -497,18 +497,17 @@ def test_runtime_scheduled_kernels(planners, oracle, dtype):
             fft = planner.plan_fft(n, d)
             assert "dyn_k1" in fft.describe(), (n, fft.describe())
             check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=5 if n < 512 else 3)
-    import os
-
     import rustfft_amd
 
-    os.environ["MI355FFT_DYN_RADER"] = "1"  # opt-in path (read at plan creation); the default for these primes is Bluestein
-    fresh = rustfft_amd.FftPlanner(dtype)
+    # run-time scheduled Rader: what a host planner gets when its Recipe says RadersAlgorithm (mi355fft_plan_create_ex,
+    # MI355FFT_ALGO_RADER) for a prime without a compiled body; AUTO plans these primes through other kernels
     for p in [5, 7, 11, 13, 17, 19, 23, 29, 31, 37, 41, 43, 53, 61, 67, 71, 73, 79, 89, 97, 127, 211, 257, 331, 1201, 2311, 3001]:
         for d in (0, 1):
-            fft = fresh.plan_fft(p, d)
-            assert ("k1<" if p <= 13 else "dyn_rader") in fft.describe()  # 5..13 have compiled single-butterfly schedules
+            fft = planner.plan_fft_with(p, d, algorithm=rustfft_amd.ALGO_RADER)
+            assert "rader" in fft.describe(), (p, fft.describe())
             check_fft_algorithm(fft, p, d, reference=oracle.plan(dtype, p, d), n=3)
-    del os.environ["MI355FFT_DYN_RADER"]
+    with pytest.raises(rustfft_amd.FftPanic, match="no GPU plan"):
+        planner.plan_fft_with(1000, 0, algorithm=rustfft_amd.ALGO_RADER)  # not prime (raders_algorithm.rs:68)
 
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
