@@ -22,7 +22,7 @@ struct DynSched {
     unsigned rcp_stride[kDynMaxPass];  // ceil(2^32 / s_p): b / s_p == mulhi(b, rcp) for b, s_p < 2^16
     unsigned rcp_tpf;
     int pitch;                     // LDS elements between sequences
-    int light;                     // 1: schedule uses only the LIGHT radix set (EMAX = 12 kernel)
+    int light;                     // radix set of the schedule: 1 = LIGHT (EMAX = 12 kernel), 2 = HEAVY (17 .. 31, EMAX = 32), 0 = full
 };
 
 MI_HD unsigned dyn_mulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
@@ -75,8 +75,10 @@ MI_HD void dyn_pass_load(const DynSched& s, int p, int f, int u, cx<T>* v, const
     });
 }
 
-// LIGHT = true compiles only the radices {2,3,4,5,6,8,9,10,12}: a kernel without the 7/11/13/16-point butterflies
+// LIGHT = 1 compiles only the radices {2,3,4,5,6,8,9,10,12}: a kernel without the 7/11/13/16-point butterflies
 // needs about half the registers, i.e. twice the resident workgroups, for lengths of the form 2^a 3^b 5^c.
+// LIGHT = 2 (HEAVY) adds the prime radices 17 .. 31 (the reference's Butterfly17 .. Butterfly31,
+// src/algorithm/butterflies.rs:1582-6241) with 32 values per thread: lengths with such a factor beyond the compiled set.
 #define MI_DYN_RADIX_SWITCH(LIGHT, RADIX, CALL)     \
     switch (RADIX) {                         \
         case 2: { constexpr int RR = 2; CALL; } break;   \
@@ -84,19 +86,24 @@ MI_HD void dyn_pass_load(const DynSched& s, int p, int f, int u, cx<T>* v, const
         case 4: { constexpr int RR = 4; CALL; } break;   \
         case 5: { constexpr int RR = 5; CALL; } break;   \
         case 6: { constexpr int RR = 6; CALL; } break;   \
-        case 7: if constexpr (!(LIGHT)) { constexpr int RR = 7; CALL; } break;   \
+        case 7: if constexpr ((LIGHT) != 1) { constexpr int RR = 7; CALL; } break;   \
         case 8: { constexpr int RR = 8; CALL; } break;   \
         case 9: { constexpr int RR = 9; CALL; } break;   \
         case 10: { constexpr int RR = 10; CALL; } break; \
-        case 11: if constexpr (!(LIGHT)) { constexpr int RR = 11; CALL; } break; \
+        case 11: if constexpr ((LIGHT) != 1) { constexpr int RR = 11; CALL; } break; \
         case 12: { constexpr int RR = 12; CALL; } break; \
-        case 13: if constexpr (!(LIGHT)) { constexpr int RR = 13; CALL; } break; \
-        case 16: if constexpr (!(LIGHT)) { constexpr int RR = 16; CALL; } break; \
+        case 13: if constexpr ((LIGHT) != 1) { constexpr int RR = 13; CALL; } break; \
+        case 16: if constexpr ((LIGHT) != 1) { constexpr int RR = 16; CALL; } break; \
+        case 17: if constexpr ((LIGHT) == 2) { constexpr int RR = 17; CALL; } break; \
+        case 19: if constexpr ((LIGHT) == 2) { constexpr int RR = 19; CALL; } break; \
+        case 23: if constexpr ((LIGHT) == 2) { constexpr int RR = 23; CALL; } break; \
+        case 29: if constexpr ((LIGHT) == 2) { constexpr int RR = 29; CALL; } break; \
+        case 31: if constexpr ((LIGHT) == 2) { constexpr int RR = 31; CALL; } break; \
         default: break;                      \
     }
 
 // X: executor (launch.h).  src(f, i), dst(f, i, value) as in engine.h.  SRC_IN_LDS as in wg_fft.
-template <class T, int EMAX, bool LIGHT, bool SRC_IN_LDS = false, class X, class SRC, class DST>
+template <class T, int EMAX, int LIGHT, bool SRC_IN_LDS = false, class X, class SRC, class DST>
 MI_HD void wg_fft_dyn(X& ex, const DynSched& s, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC src, DST dst) {
     cx<T>* lds = (cx<T>*)lds_raw;
     for (int p = 0; p < s.np; ++p) {

@@ -341,7 +341,7 @@ MI_HD void bluestein_body(X& ex, const BluesteinParams<T>& p, long long block, v
 }
 
 // ---- run-time scheduled batched transform (13-smooth lengths) ------------------------------------------------
-template <class T, int EMAX, bool LIGHT, class X>
+template <class T, int EMAX, int LIGHT, class X>
 MI_HD void dyn_k1_body(X& ex, const DynK1Params<T>& p, long long block, void* lds) {
     const DynSched& s = p.s;
     const long long fft0 = block * s.f;
@@ -368,7 +368,7 @@ MI_HD void dyn_k1_body(X& ex, const DynK1Params<T>& p, long long block, void* ld
 }
 
 // ---- run-time scheduled Rader (any prime p with 13-smooth p - 1); same steps as rader_body ---------------------
-template <class T, int EMAX, bool LIGHT, class X>
+template <class T, int EMAX, int LIGHT, class X>
 MI_HD void dyn_rader_body(X& ex, const DynRaderParams<T>& p, long long block, void* lds) {
     const DynSched& s = p.s;
     const int M = s.n, P = s.n + 1, PITCH = s.pitch, F = s.f, NT = s.f * s.tpf;

@@ -228,16 +228,18 @@ template <class T, class S, int F, bool FIRST, int FUSE = 0, bool SPLIT = false>
     };
     return e;
 }
-constexpr int kDynEmax = 16, kDynEmaxLight = 12;
-template <class T, bool LIGHT> __global__ __launch_bounds__(512) void dyn_k1_kernel(DynK1Params<T> p) {
+constexpr int kDynEmax = 16, kDynEmaxLight = 12, kDynEmaxHeavy = 32;
+constexpr int dyn_emax(int set) { return set == 1 ? kDynEmaxLight : set == 2 ? kDynEmaxHeavy : kDynEmax; }
+// the HEAVY set (prime radices 17 .. 31, 32 values per thread) runs workgroups of at most 256 threads: 256 VGPRs each
+template <class T, int LIGHT> __global__ __launch_bounds__(LIGHT == 2 ? 256 : 512) void dyn_k1_kernel(DynK1Params<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    DevExec<T, LIGHT ? kDynEmaxLight : kDynEmax> ex;
-    dyn_k1_body<T, LIGHT ? kDynEmaxLight : kDynEmax, LIGHT>(ex, p, (long long)blockIdx.x, smem);
+    DevExec<T, dyn_emax(LIGHT)> ex;
+    dyn_k1_body<T, dyn_emax(LIGHT), LIGHT>(ex, p, (long long)blockIdx.x, smem);
 }
-template <class T, bool LIGHT> __global__ __launch_bounds__(512) void dyn_rader_kernel(DynRaderParams<T> p) {
+template <class T, int LIGHT> __global__ __launch_bounds__(LIGHT == 2 ? 256 : 512) void dyn_rader_kernel(DynRaderParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    DevExec<T, LIGHT ? kDynEmaxLight : kDynEmax> ex;
-    dyn_rader_body<T, LIGHT ? kDynEmaxLight : kDynEmax, LIGHT>(ex, p, (long long)blockIdx.x, smem);
+    DevExec<T, dyn_emax(LIGHT)> ex;
+    dyn_rader_body<T, dyn_emax(LIGHT), LIGHT>(ex, p, (long long)blockIdx.x, smem);
 }
 // the run-time scheduled kernels take their block size and LDS bytes from the schedule in the parameter block
 template <class T> KernelEntry make_dyn_k1(int prec) {
@@ -248,14 +250,15 @@ template <class T> KernelEntry make_dyn_k1(int prec) {
     e.launch = [](const void* params, long long grid, void* stream) {
         const DynK1Params<T>* p = (const DynK1Params<T>*)params;
         void* args[] = {const_cast<void*>(params)};
-        (void)hipLaunchKernel(p->s.light ? (const void*)dyn_k1_kernel<T, true> : (const void*)dyn_k1_kernel<T, false>,
-                              dim3((unsigned)grid), dim3(p->s.f * p->s.tpf), args, (size_t)p->s.f * p->s.pitch * sizeof(cx<T>),
+        const void* fn = p->s.light == 1 ? (const void*)dyn_k1_kernel<T, 1> : p->s.light == 2 ? (const void*)dyn_k1_kernel<T, 2> : (const void*)dyn_k1_kernel<T, 0>;
+        (void)hipLaunchKernel(fn, dim3((unsigned)grid), dim3(p->s.f * p->s.tpf), args, (size_t)p->s.f * p->s.pitch * sizeof(cx<T>),
                               (hipStream_t)stream);
     };
     e.prepare = []() -> int {
-        int a = (int)hipFuncSetAttribute((const void*)dyn_k1_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        int b = (int)hipFuncSetAttribute((const void*)dyn_k1_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        return a ? a : b;
+        int a = (int)hipFuncSetAttribute((const void*)dyn_k1_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        int b = (int)hipFuncSetAttribute((const void*)dyn_k1_kernel<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        int c = (int)hipFuncSetAttribute((const void*)dyn_k1_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return a ? a : b ? b : c;
     };
     return e;
 }
@@ -267,14 +270,15 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
     e.launch = [](const void* params, long long grid, void* stream) {
         const DynRaderParams<T>* p = (const DynRaderParams<T>*)params;
         void* args[] = {const_cast<void*>(params)};
-        (void)hipLaunchKernel(p->s.light ? (const void*)dyn_rader_kernel<T, true> : (const void*)dyn_rader_kernel<T, false>,
-                              dim3((unsigned)grid), dim3(p->s.f * p->s.tpf), args,
+        const void* fn = p->s.light == 1 ? (const void*)dyn_rader_kernel<T, 1> : p->s.light == 2 ? (const void*)dyn_rader_kernel<T, 2> : (const void*)dyn_rader_kernel<T, 0>;
+        (void)hipLaunchKernel(fn, dim3((unsigned)grid), dim3(p->s.f * p->s.tpf), args,
                               (size_t)p->s.f * (p->s.pitch + p->s.n + 1) * sizeof(cx<T>), (hipStream_t)stream);
     };
     e.prepare = []() -> int {
-        int a = (int)hipFuncSetAttribute((const void*)dyn_rader_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        int b = (int)hipFuncSetAttribute((const void*)dyn_rader_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        return a ? a : b;
+        int a = (int)hipFuncSetAttribute((const void*)dyn_rader_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        int b = (int)hipFuncSetAttribute((const void*)dyn_rader_kernel<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        int c = (int)hipFuncSetAttribute((const void*)dyn_rader_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return a ? a : b ? b : c;
     };
     return e;
 }
@@ -437,7 +441,7 @@ template <class T, class S, int F, bool FIRST, int FUSE = 0, bool SPLIT = false>
     e.prepare = []() -> int { return 0; };
     return e;
 }
-constexpr int kDynEmax = 16, kDynEmaxLight = 12;
+constexpr int kDynEmax = 16, kDynEmaxLight = 12, kDynEmaxHeavy = 32;
 template <class T> KernelEntry make_dyn_k1(int prec) {
     KernelEntry e{};
     e.kind = KIND_DYN_K1;
@@ -447,11 +451,13 @@ template <class T> KernelEntry make_dyn_k1(int prec) {
         const DynK1Params<T>* p = (const DynK1Params<T>*)params;
         std::vector<char> lds((size_t)p->s.f * p->s.pitch * sizeof(cx<T>) + 64, (char)0x5a);
         for (long long b = 0; b < grid; ++b) {
-            HostExec<T, kDynEmax> ex(p->s.f * p->s.tpf);
-            if (p->s.light)
-                dyn_k1_body<T, kDynEmaxLight, true>(ex, *p, b, lds.data());
+            HostExec<T, kDynEmaxHeavy> ex(p->s.f * p->s.tpf);
+            if (p->s.light == 1)
+                dyn_k1_body<T, kDynEmaxLight, 1>(ex, *p, b, lds.data());
+            else if (p->s.light == 2)
+                dyn_k1_body<T, kDynEmaxHeavy, 2>(ex, *p, b, lds.data());
             else
-                dyn_k1_body<T, kDynEmax, false>(ex, *p, b, lds.data());
+                dyn_k1_body<T, kDynEmax, 0>(ex, *p, b, lds.data());
         }
     };
     e.prepare = []() -> int { return 0; };
@@ -466,11 +472,13 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
         const DynRaderParams<T>* p = (const DynRaderParams<T>*)params;
         std::vector<char> lds((size_t)p->s.f * (p->s.pitch + p->s.n + 1) * sizeof(cx<T>) + 64, (char)0x5a);
         for (long long b = 0; b < grid; ++b) {
-            HostExec<T, kDynEmax> ex(p->s.f * p->s.tpf);
-            if (p->s.light)
-                dyn_rader_body<T, kDynEmaxLight, true>(ex, *p, b, lds.data());
+            HostExec<T, kDynEmaxHeavy> ex(p->s.f * p->s.tpf);
+            if (p->s.light == 1)
+                dyn_rader_body<T, kDynEmaxLight, 1>(ex, *p, b, lds.data());
+            else if (p->s.light == 2)
+                dyn_rader_body<T, kDynEmaxHeavy, 2>(ex, *p, b, lds.data());
             else
-                dyn_rader_body<T, kDynEmax, false>(ex, *p, b, lds.data());
+                dyn_rader_body<T, kDynEmax, 0>(ex, *p, b, lds.data());
         }
     };
     e.prepare = []() -> int { return 0; };

@@ -74,6 +74,26 @@ void ensure_registry() {
         register_smooth2_f64_1(r);
         register_smooth2_f64_2(r);
         register_smooth2_f64_3(r);
+        register_smooth3_f32_0(r);
+        register_smooth3_f32_1(r);
+        register_smooth3_f32_2(r);
+        register_smooth3_f32_3(r);
+        register_smooth3_f32_4(r);
+        register_smooth3_f32_5(r);
+        register_smooth3_f32_6(r);
+        register_smooth3_f32_7(r);
+        register_smooth3_f64_0(r);
+        register_smooth3_f64_1(r);
+        register_smooth3_f64_2(r);
+        register_smooth3_f64_3(r);
+        register_rader_f32_0(r);
+        register_rader_f32_1(r);
+        register_rader_f32_2(r);
+        register_rader_f32_3(r);
+        register_rader_f64_0(r);
+        register_rader_f64_1(r);
+        register_rader_f64_2(r);
+        register_rader_f64_3(r);
     });
 }
 
@@ -306,18 +326,24 @@ static uint64_t primitive_root(uint64_t p) {
 static bool build_dyn_sched(size_t n, size_t esz, size_t extra_lds_elems_per_seq, DynSched& s) {
     static const int allowed_full[] = {16, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
     static const int allowed_light[] = {12, 10, 9, 8, 6, 5, 4, 3, 2};  // dyn_engine.h LIGHT set (lengths 2^a 3^b 5^c)
+    static const int allowed_heavy[] = {31, 29, 23, 19, 17, 16, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};  // HEAVY set: 32 values per thread
     if (n < 2 || n > 16384) return false;
     std::vector<int> radices;
-    bool light = true;
+    int set = 1;  // 1 light, 0 full, 2 heavy
     {
         size_t t = n;
         for (int q : {2, 3, 5})
             while (t % q == 0) t /= q;
-        light = (t == 1);
+        if (t != 1) {
+            set = 0;
+            for (int q : {17, 19, 23, 29, 31})
+                if (n % q == 0) set = 2;
+        }
     }
-    const int* allowed = light ? allowed_light : allowed_full;
-    const int n_allowed = light ? 9 : 13;
-    const int emax = light ? 12 : 16;
+    const int* allowed = set == 1 ? allowed_light : set == 2 ? allowed_heavy : allowed_full;
+    const int n_allowed = set == 1 ? 9 : set == 2 ? 18 : 13;
+    const int emax = set == 1 ? 12 : set == 2 ? 32 : 16;
+    const int max_threads = set == 2 ? 256 : 512;
     size_t rem = n;
     while (rem > 1) {
         int pick = 0;
@@ -326,7 +352,7 @@ static bool build_dyn_sched(size_t n, size_t esz, size_t extra_lds_elems_per_seq
                 pick = allowed[i];
                 break;
             }
-        if (!pick) return false;  // a prime factor above 13
+        if (!pick) return false;  // a prime factor above 31 (13 for the other sets)
         radices.push_back(pick);
         rem /= pick;
     }
@@ -334,7 +360,7 @@ static bool build_dyn_sched(size_t n, size_t esz, size_t extra_lds_elems_per_seq
     std::sort(radices.begin(), radices.end(), std::greater<int>());
     s = DynSched{};
     s.n = (int)n;
-    s.light = light ? 1 : 0;
+    s.light = set;
     s.np = (int)radices.size();
     int tpf = 1, stride = 1, off = 0;
     for (int p = 0; p < s.np; ++p) {
@@ -348,7 +374,7 @@ static bool build_dyn_sched(size_t n, size_t esz, size_t extra_lds_elems_per_seq
         if (p >= 1) off += (R - 1) * stride;
         stride *= R;
     }
-    if (tpf > 512) return false;  // the kernels are compiled for at most 512 threads per workgroup
+    if (tpf > max_threads) return false;  // the kernels are compiled for at most 512 (HEAVY: 256) threads per workgroup
     s.tpf = tpf;
     s.rcp_tpf = tpf > 1 ? (unsigned)((((unsigned long long)1 << 32) + tpf - 1) / tpf) : 0;
     for (int p = 0; p < s.np; ++p) s.bpt[p] = (s.nb[p] + tpf - 1) / tpf;
@@ -356,8 +382,8 @@ static bool build_dyn_sched(size_t n, size_t esz, size_t extra_lds_elems_per_seq
     const size_t per_seq = ((size_t)s.pitch + extra_lds_elems_per_seq) * esz;
     int f = std::max(1, 256 / tpf);
     while (f > 1 && (size_t)f * per_seq > 64 * 1024) --f;
-    while (f > 1 && f * tpf > 512) --f;
-    if ((size_t)f * per_seq > 150 * 1024 || f * tpf > 512) return false;
+    while (f > 1 && f * tpf > max_threads) --f;
+    if ((size_t)f * per_seq > 150 * 1024 || f * tpf > max_threads) return false;
     s.f = f;
     return true;
 }
@@ -760,7 +786,10 @@ template <class T> static int build_plan_t(Plan& plan) {
     if (direct_ok && env_int("MI355FFT_NO_DYN") == 0) {
         DynSched ds;
         const KernelEntry* dk = find_kind(KIND_DYN_K1, plan.prec);
-        if (dk && build_dyn_sched(n, 2 * sizeof(T), 0, ds)) {
+        // measured (profiles/r2/pr_vs_bs_*.jsonl): the HEAVY set (prime radices 17 .. 31, 32 values per thread) runs at
+        // 0.5 - 1.0 TB/s -- behind the one-kernel Bluestein (1.1 - 1.3, n <= 4096), ahead of the two-kernel one (0.5 - 0.6)
+        const bool heavy_loses = algo == MI355FFT_ALGO_AUTO && n <= 4096;
+        if (dk && build_dyn_sched(n, 2 * sizeof(T), 0, ds) && !(ds.light == 2 && heavy_loses)) {
             if (dk->prepare()) return MI355FFT_ERR_HIP;
             plan.kind = PLAN_SINGLE;
             PassDesc pd{};

@@ -85,6 +85,29 @@ void register_smooth2_f64_1(std::vector<KernelEntry>&);
 void register_smooth2_f64_2(std::vector<KernelEntry>&);
 void register_smooth2_f64_3(std::vector<KernelEntry>&);
 
+// generated: compiled schedules for the lengths <= 2048 (f64: 1024) with a prime factor 17 .. 31 (tools/gen_smooth_kernels.py main_primes)
+void register_smooth3_f32_0(std::vector<KernelEntry>&);
+void register_smooth3_f32_1(std::vector<KernelEntry>&);
+void register_smooth3_f32_2(std::vector<KernelEntry>&);
+void register_smooth3_f32_3(std::vector<KernelEntry>&);
+void register_smooth3_f32_4(std::vector<KernelEntry>&);
+void register_smooth3_f32_5(std::vector<KernelEntry>&);
+void register_smooth3_f32_6(std::vector<KernelEntry>&);
+void register_smooth3_f32_7(std::vector<KernelEntry>&);
+void register_smooth3_f64_0(std::vector<KernelEntry>&);
+void register_smooth3_f64_1(std::vector<KernelEntry>&);
+void register_smooth3_f64_2(std::vector<KernelEntry>&);
+void register_smooth3_f64_3(std::vector<KernelEntry>&);
+// generated: compiled Rader bodies for the primes <= 4096 with 13-smooth p - 1 (tools/gen_rader_kernels.py)
+void register_rader_f32_0(std::vector<KernelEntry>&);
+void register_rader_f32_1(std::vector<KernelEntry>&);
+void register_rader_f32_2(std::vector<KernelEntry>&);
+void register_rader_f32_3(std::vector<KernelEntry>&);
+void register_rader_f64_0(std::vector<KernelEntry>&);
+void register_rader_f64_1(std::vector<KernelEntry>&);
+void register_rader_f64_2(std::vector<KernelEntry>&);
+void register_rader_f64_3(std::vector<KernelEntry>&);
+
 template <class S> inline void fill_sched(KernelEntry& e) {
     e.tpf = S::TPF;
     e.np = S::NP;

@@ -255,8 +255,8 @@ def test_runtime_scheduled_kernels(emu_planner, oracle, dtype):
     primes = [p for p in range(5, 100) if all(p % q for q in range(2, int(p**0.5) + 1))] + [127, 211, 257, 331, 1201, 2311, 3001]
     import rustfft_amd
 
-    def smooth13(v):
-        for q in (2, 3, 5, 7, 11, 13):
+    def smooth13(v):  # (31-smooth since the run-time scheduled kernels know the prime radices 17 .. 31)
+        for q in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31):
             while v % q == 0:
                 v //= q
         return v == 1
@@ -377,3 +377,29 @@ def test_host_planner_options(emu_planner, oracle):
         check_fft_algorithm(fft, p, d, reference=oracle.plan(dtype, p, d), n=3)
     with pytest.raises(rustfft_amd.FftPanic, match="needs algorithm"):
         planner.plan_fft_with(1009, 0, rader_inner_fft_data=np.zeros(1008, dtype=dtype))
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_prime_radices_17_to_31(emu_planner, oracle, dtype):
+    """The reference's Butterfly17 .. Butterfly31 (src/algorithm/butterflies.rs:1582-6241) as in-register prime radices:
+    lengths with such a factor run as mixed-radix kernels -- compiled schedules up to 1024, the run-time scheduled HEAVY
+    kernel above -- and no longer through Bluestein."""
+    planner = emu_planner(dtype)
+    for n in (17, 19, 23, 29, 31, 34, 51, 93, 289, 323, 437, 899, 961, 992, 1023):
+        for d in (0, 1):
+            fft = planner.plan_fft(n, d)
+            assert fft.describe().startswith("k1<%d," % n), (n, fft.describe())
+            check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=3)
+    import rustfft_amd
+
+    for n in (1088, 1734, 2465, 3553, 4352, 6448):
+        for d in (0, 1):
+            fft = planner.plan_fft(n, d)
+            if n <= 2048 and dtype == np.complex64:
+                assert fft.describe().startswith("k1<%d," % n), (n, fft.describe())  # compiled up to 2048 in f32
+            elif n <= 4096:  # the one-kernel Bluestein measured faster than the run-time scheduled HEAVY kernel ...
+                assert "bluestein" in fft.describe(), (n, fft.describe())
+                fft = planner.plan_fft_with(n, d, algorithm=rustfft_amd.ALGO_MIXED_RADIX)  # ... which a host planner can still ask for
+            assert "dyn_k1" in fft.describe() or fft.describe().startswith("k1<"), (n, fft.describe())
+            check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=2)
+    assert "bluestein" in planner.plan_fft(4913, 0).describe()  # 17^3: three 17-point sub-passes need 289 threads per row

@@ -147,8 +147,46 @@ def main_big():
         print(len(sizes), "lengths in (4096, 16384] (f32: 32768],", tag)
 
 
+BIG_PRIMES = [31, 29, 23, 19, 17]
+
+
+def schedule31(n, emax=32, max_passes=5):
+    """Lengths with a prime factor 17 .. 31 (the reference's Butterfly17 .. Butterfly31, src/algorithm/butterflies.rs:1582-6241):
+    the prime radices join the set, 32 values per thread so that one 31-point butterfly fits a thread."""
+    global RADICES
+    saved = RADICES
+    RADICES = BIG_PRIMES + saved
+    try:
+        return schedule(n, emax, max_passes)
+    finally:
+        RADICES = saved
+
+
+def main_primes(limits=(("f32", "float", 32, 8, 2048, 8), ("f64", "double", 64, 16, 1024, 4))):
+    """kernels_smooth3_*: compiled schedules for the 31-smooth lengths <= limit that have a prime factor in 17 .. 31
+    (measured on MI355X: 4.0 - 5.3 TB/s against 1.2 - 2.0 through Bluestein and 0.5 - 1.0 through the run-time scheduled
+    kernel; f32 up to 2048, f64 up to 1024 -- the build time is what bounds the set)."""
+    for tag, ty, prec, esz, limit, nfiles in limits:
+        s13 = set(smooth(limit, [2, 3, 5, 7, 11, 13]))
+        sizes = [x for x in smooth(limit, [2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31]) if x not in s13]
+        for ci in range(nfiles):
+            lines = []
+            for n in sizes[ci::nfiles]:
+                rad, tpf = schedule31(n)
+                f = max(1, min(256 // tpf, (48 * 1024) // ((n + n // 8 + 2) * esz)))  # <= 256 threads: the prime butterflies want > 128 VGPRs
+                lines.append(f"    MI_K1({ty}, {prec}, {f}, false, {n}, {tpf}, {', '.join(map(str, rad))});")
+            path = os.path.join(ROOT, "rustfft_amd", "csrc", f"kernels_smooth3_{tag}_{ci}.hip")
+            with open(path, "w") as fh:
+                fh.write(f"// GENERATED by tools/gen_smooth_kernels.py — do not edit.  Compiled K1 schedules for the lengths <= {limit} with a prime\n"
+                         f"// factor 17 .. 31 (in-register prime butterflies; part {ci + 1} of {nfiles}), Complex<{ty}>.\n"
+                         '#include "launch.h"\nnamespace mi355 {\n'
+                         f"void register_smooth3_{tag}_{ci}(std::vector<KernelEntry>& reg) {{\n" + "\n".join(lines) + "\n}\n}  // namespace mi355\n")
+        print(len(sizes), "lengths with a factor 17 .. 31, <=", limit, tag)
+
+
 def main():
     main_big()
+    main_primes()
     sizes = [x for x in smooth(4096, [2, 3, 5, 7, 11, 13]) if x > 2 and (x & (x - 1)) and x != 1200]
     for tag, ty, prec, esz in (("f32", "float", 32, 8), ("f64", "double", 64, 16)):
         chunks = [sizes[i::NFILES] for i in range(NFILES)]
