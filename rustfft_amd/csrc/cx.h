@@ -27,6 +27,20 @@ namespace mi355 {
 template <class T> struct cx {
     T re, im;
 };
+
+// Register barrier over eight complex values: an empty volatile asm that redefines them.  Volatile asm statements keep
+// their order, so arithmetic that produces these values stays above the statement and arithmetic that consumes them
+// stays below it -- a wall the IR-level vectoriser cannot pair instructions across (MI_SCHED_FENCE only binds the machine
+// scheduler; without this the SLP vectoriser fuses neighbouring butterflies into packed operations, doubles the live
+// twiddles and spills the 32-values-per-thread tiles).  No instruction is emitted.  No-op on the host.
+template <class T> MI_HD void reg_wall8(cx<T>* x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(x[0].re), "+v"(x[0].im), "+v"(x[1].re), "+v"(x[1].im), "+v"(x[2].re), "+v"(x[2].im), "+v"(x[3].re), "+v"(x[3].im),
+                      "+v"(x[4].re), "+v"(x[4].im), "+v"(x[5].re), "+v"(x[5].im), "+v"(x[6].re), "+v"(x[6].im), "+v"(x[7].re), "+v"(x[7].im));
+#else
+    (void)x;
+#endif
+}
 template <class T> MI_HD cx<T> operator+(cx<T> a, cx<T> b) { return {a.re + b.re, a.im + b.im}; }
 template <class T> MI_HD cx<T> operator-(cx<T> a, cx<T> b) { return {a.re - b.re, a.im - b.im}; }
 template <class T> MI_HD cx<T> operator*(cx<T> a, cx<T> b) {

@@ -23,7 +23,7 @@
 
 namespace mi355 {
 
-enum Map { MAP_EF = 0, MAP_FF = 1 };
+enum Map { MAP_EF = 0, MAP_FF = 1, MAP_FFP = 2 };
 
 
 
@@ -138,10 +138,17 @@ template <class S> constexpr int lds_step_const(int k, int step, int span /* s_p
     return -1;
 }
 
+//   MAP_FFP  fft-fastest, PAIRED: as MAP_FF, but the slots u and u + TPF/2 of one column sit in lanes l and l + 32 of
+//            one wave, so the first exchange of a pair-fused schedule is a v_permlane32_swap instead of an LDS round trip
 template <Map M, int F, int TPF> MI_HD void map_tid(int tid, int& f, int& u) {
     if constexpr (M == MAP_EF) {
         u = tid % TPF;
         f = tid / TPF;
+    } else if constexpr (M == MAP_FFP) {
+        static_assert(F <= 32 && 32 % F == 0 && TPF % 2 == 0, "paired map: a 32-lane half holds whole groups of F columns");
+        const int lane = tid & 63, w = tid >> 6;
+        f = lane % F;
+        u = w * (32 / F) + (lane & 31) / F + (TPF / 2) * (lane >> 5);
     } else {
         f = tid % F;
         u = tid / F;
@@ -263,6 +270,62 @@ template <class T, class S, int P, int PART, class E> MI_HD void lds_gather(cx<T
                     v[m * R + k].im = ldsf[o];
             });
         }
+    });
+}
+
+// ---- pair-fused first two sub-passes ------------------------------------------------------------------------------------
+// Schedules that open with two radix-8 sub-passes and hold 32 values per thread (N = 32 TPF; the 512- and 1024-row column
+// tiles): sub-pass 1's butterfly b' reads y[b' + k' N/8], i.e. output (b' mod 8) of the sub-pass-0 butterflies
+// b'/8 + k' TPF/2 -- which the two threads u = g and u = g + TPF/2 hold between them (g = u mod TPF/2; thread h = u div
+// TPF/2 has k' = 2m + h in its butterfly m).  With the paired lane map those two threads are lanes l and l + 32 of one
+// wave: sixteen v_permlane32_swap per plane replace the whole first LDS exchange (32 ds_write + 32 ds_read per plane and
+// two barriers; four barriers with the split exchange).  After the swap BOTH threads find input k' of their butterfly j
+// (b' = 8 g + 4 h + j, j < 4) in register slot (k'/2) 8 + j + 4 (k' & 1), so the code is lane-uniform; the outputs go back to the
+// same slots and from there to LDS in the ordinary exchange-1 layout, which sub-pass 2 gathers as usual.
+template <class S> constexpr bool pair_fusable() {
+    return S::NP >= 3 && S::R[0] == 8 && S::R[1] == 8 && S::bpt(0) == 4 && S::bpt(1) == 4 && S::N == 32 * S::TPF && S::all_pow2() && S::emax() > 16;
+}
+template <class T, class S> MI_HD void pair_subpass1(cx<T>* v, int u, const cx<T>* MI_RESTRICT tw) {
+    constexpr int H = S::TPF / 2;
+    const int h = u / H;
+    const cx<T>* t = tw + S::tw_offset(1) + 4 * h;  // w_64^{(4h + j) k'} at [(k' - 1) 8 + 4h + j]
+    static_for<0, 4>([&](auto J_) {
+        constexpr int j = J_;
+        cx<T> x[8];
+        static_for<0, 8>([&](auto K_) {
+            constexpr int k = K_;
+            x[k] = v[(k / 2) * 8 + j + 4 * (k & 1)];
+        });
+        reg_wall8(x);  // butterfly j starts below this point ...
+        static_for<1, 8>([&](auto K_) {
+            constexpr int k = K_;
+            x[k] = x[k] * t[(k - 1) * 8 + j];
+        });
+        butterfly<8>(x);
+        reg_wall8(x);  // ... and is complete above this one: neighbouring butterflies cannot be fused into packed operations
+        static_for<0, 8>([&](auto Q_) {
+            constexpr int q = Q_;
+            v[(q / 2) * 8 + j + 4 * (q & 1)] = x[q];
+        });
+        MI_SCHED_FENCE();
+    });
+}
+// exchange 1 (written by sub-pass 1) from the pair-fused register layout: output q of butterfly b' = 8 g + 4 h + j lands at
+// y[g 64 + (4 h + j) + 8 q]; linear layout (one padding slot per 32 elements): 66 g + 4 h + [j + 8 q + (q >= 4)]
+template <class T, class S, int PART, class E> MI_HD void pair_scatter(const cx<T>* v, int u, E* ldsf) {
+    constexpr int H = S::TPF / 2;
+    const int g = u % H, h = u / H, pbase = 66 * g + 4 * h;
+    static_for<0, 4>([&](auto J_) {
+        constexpr int j = J_;
+        static_for<0, 8>([&](auto Q_) {
+            constexpr int q = Q_, slot = (q / 2) * 8 + j + 4 * (q & 1), off = j + 8 * q + (q >= 4 ? 1 : 0);
+            if constexpr (PART == 0)
+                ldsf[pbase + off] = v[slot];
+            else if constexpr (PART == 1)
+                ldsf[pbase + off] = v[slot].re;
+            else
+                ldsf[pbase + off] = v[slot].im;
+        });
     });
 }
 
@@ -391,6 +454,7 @@ template <class T, class S, int F, bool SPLIT, int PM = 1> constexpr size_t lds_
 template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, bool SRC_IN_LDS = false, int PM = 1, int ABL = 0, int TWREG = -1, bool TWSTAGE = false, class X, class SRC, class DST>
 MI_HD void wg_fft(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC src, DST dst) {
     static_assert(S::valid(), "radices must multiply to N");
+    static_assert(MIN != MAP_FFP || (pair_fusable<S>() && !SRC_IN_LDS && TWREG < 0 && sizeof(T) == 4), "the paired map is the pair-fused path");
     constexpr int R0 = S::R[0], NB0 = S::nb(0), BPT0 = S::bpt(0);
     // inputs of sub-pass 0 straight from the source
     ex.for_threads([&](int tid, cx<T>* v) {
@@ -410,7 +474,56 @@ MI_HD void wg_fft(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC src, DS
         }
     });
     if constexpr (SRC_IN_LDS) ex.barrier();
-    wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, 0, TWREG, TWSTAGE>(ex, lds_raw, tw, src, dst);
+    if constexpr (MIN == MAP_FFP) {
+        constexpr Map MQ = pass_map<S, 2, MIN, MOUT>();
+        constexpr int PITCH = S::template pitch_for<PM>();
+        ex.for_threads([&](int tid, cx<T>* v) {
+            int f, u;
+            map_tid<MAP_FFP, F, S::TPF>(tid, f, u);
+            compute_pass<T, S, 0>(v, u, tw);
+        });
+        ex.pair_swap();  // v[m 8 + k] of the upper half-wave <-> v[m 8 + k + 4] of the lower one, m, k < 4
+        ex.for_threads([&](int tid, cx<T>* v) {
+            int f, u;
+            map_tid<MAP_FFP, F, S::TPF>(tid, f, u);
+            pair_subpass1<T, S>(v, u, tw);
+            if constexpr (!SPLIT)
+                pair_scatter<T, S, 0>(v, u, (cx<T>*)lds_raw + f * PITCH);
+            else
+                pair_scatter<T, S, 1>(v, u, (T*)lds_raw + f * PITCH);
+        });
+        ex.barrier();
+        if constexpr (!SPLIT) {
+            ex.for_threads([&](int tid, cx<T>* v) {
+                int f, u;
+                map_tid<MQ, F, S::TPF>(tid, f, u);
+                lds_gather<T, S, 2, 0>(v, u, (const cx<T>*)lds_raw + f * PITCH);
+            });
+            ex.barrier();
+        } else {
+            ex.for_threads([&](int tid, cx<T>* v) {
+                int f, u;
+                map_tid<MQ, F, S::TPF>(tid, f, u);
+                lds_gather<T, S, 2, 1>(v, u, (const T*)lds_raw + f * PITCH);
+            });
+            ex.barrier();
+            ex.for_threads([&](int tid, cx<T>* v) {
+                int f, u;
+                map_tid<MAP_FFP, F, S::TPF>(tid, f, u);
+                pair_scatter<T, S, 2>(v, u, (T*)lds_raw + f * PITCH);
+            });
+            ex.barrier();
+            ex.for_threads([&](int tid, cx<T>* v) {
+                int f, u;
+                map_tid<MQ, F, S::TPF>(tid, f, u);
+                lds_gather<T, S, 2, 2>(v, u, (const T*)lds_raw + f * PITCH);
+            });
+            ex.barrier();
+        }
+        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, 2, TWREG, TWSTAGE>(ex, lds_raw, tw, src, dst);
+    } else {
+        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, 0, TWREG, TWSTAGE>(ex, lds_raw, tw, src, dst);
+    }
 }
 
 }  // namespace mi355

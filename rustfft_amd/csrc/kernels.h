@@ -198,7 +198,7 @@ MI_HD void k2_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     };
     // first pass: lanes walk across the tile's columns on the way in and along each sequence on the way
     // out (the F*R output block is contiguous); later passes: across columns both ways
-    wg_fft<T, S, F, MAP_FF, FIRST ? MAP_EF : MAP_FF, SPLIT, false, k2_pitch_mod(F), (ABL & 15)>(ex, lds, p.tw, src, dst);
+    wg_fft<T, S, F, (ABL & 64) ? MAP_FFP : MAP_FF, FIRST ? MAP_EF : MAP_FF, SPLIT, false, k2_pitch_mod(F), (ABL & 15)>(ex, lds, p.tw, src, dst);
 }
 
 // ---- large-N pass for lengths that are not powers of two ------------------------------------------------------------

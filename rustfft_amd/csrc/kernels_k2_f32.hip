@@ -25,6 +25,15 @@ void register_k2_f32(std::vector<KernelEntry>& reg) {
     MI_K2_LATER(float, 32, 16, true, 2048, 64, 8, 16, 16);
     MI_K2V(1, float, 32, 8, false, 1024, 64, 16, 16, 4);   // tuning: 64-byte row segments paired per XCD, full-complex exchange
     MI_K2V(3, float, 32, 8, true, 1024, 32, 8, 8, 16);     // tuning: 8-column tiles (paired per XCD), 256 threads, four workgroups per CU
+    // tuning: pair-fused first two sub-passes (v_permlane32_swap instead of the first LDS exchange)
+#if defined(MI355_TUNING)
+    MI_K2P_FIRST(float, 32, 16, true, 1024, 32, 8, 8, 16);
+    reg.back().variant = 12;
+    MI_K2P_LATER(float, 32, 16, true, 1024, 32, 8, 8, 16);
+    reg.back().variant = 12;
+    MI_K2P_LATER(float, 32, 32, true, 512, 16, 8, 8, 8);
+    reg.back().variant = 12;
+#endif
     MI_K2V(10, float, 32, 16, true, 1024, 32, 32, 32);     // tuning: two radix-32 sub-passes, one exchange (the later pass spills)
     MI_K2V(11, float, 32, 16, true, 1024, 32, 4, 16, 16);  // tuning: radix-4 first sub-pass (eight butterflies per thread)
     // ablation probes of the default 1024-row tile (wrong results by design; MI355FFT_VARIANT=5..8, tuning only)

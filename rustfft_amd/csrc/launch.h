@@ -16,6 +16,24 @@ template <class T, int NREG> struct DevExec {
     template <class Fn> __device__ __forceinline__ void for_threads(Fn&& fn) { fn((int)threadIdx.x, v); }
     __device__ __forceinline__ void barrier() { __syncthreads(); }
     __device__ __forceinline__ void relaunder() {}
+    // engine.h pair-fused schedules: slot m 8 + k of lanes 32..63 <-> slot m 8 + k + 4 of lanes 0..31 (m, k < 4), both planes.
+    // v_permlane32_swap_b32 vdst, src swaps vdst[32..63] with src[0..31]; the s_nop covers the VALU-write -> permlane-read
+    // hazard the compiler does not pad inside an asm statement (cdna_hip_programming.md T21).
+    __device__ __forceinline__ void pair_swap() {
+        if constexpr (sizeof(T) == 4 && NREG >= 32) {
+            static_for<0, 4>([&](auto M_) {
+                constexpr int m = M_;
+                asm volatile(
+                    "s_nop 1\n\t"
+                    "v_permlane32_swap_b32 %0, %8\n\tv_permlane32_swap_b32 %1, %9\n\tv_permlane32_swap_b32 %2, %10\n\tv_permlane32_swap_b32 %3, %11\n\t"
+                    "v_permlane32_swap_b32 %4, %12\n\tv_permlane32_swap_b32 %5, %13\n\tv_permlane32_swap_b32 %6, %14\n\tv_permlane32_swap_b32 %7, %15"
+                    : "+v"(v[m * 8 + 0].re), "+v"(v[m * 8 + 0].im), "+v"(v[m * 8 + 1].re), "+v"(v[m * 8 + 1].im), "+v"(v[m * 8 + 2].re),
+                      "+v"(v[m * 8 + 2].im), "+v"(v[m * 8 + 3].re), "+v"(v[m * 8 + 3].im), "+v"(v[m * 8 + 4].re), "+v"(v[m * 8 + 4].im),
+                      "+v"(v[m * 8 + 5].re), "+v"(v[m * 8 + 5].im), "+v"(v[m * 8 + 6].re), "+v"(v[m * 8 + 6].im), "+v"(v[m * 8 + 7].re),
+                      "+v"(v[m * 8 + 7].im));
+            });
+        }
+    }
 };
 // Executor for bodies that loop over many sequences: relaunder() makes the thread index opaque to the optimiser from
 // there on, so the (cheap) index arithmetic is redone per sequence instead of being hoisted out of the loop into
@@ -26,6 +44,7 @@ template <class T, int NREG> struct DevExecLoop {
     template <class Fn> __device__ __forceinline__ void for_threads(Fn&& fn) { fn(tid, v); }
     __device__ __forceinline__ void barrier() { __syncthreads(); }
     __device__ __forceinline__ void relaunder() { asm volatile("" : "+v"(tid)); }
+    __device__ __forceinline__ void pair_swap() {}
 };
 
 template <class T, class S, int F, bool SPLIT, int ABL = 0>
@@ -36,6 +55,7 @@ __global__ __launch_bounds__(F* S::TPF) void k1_kernel(K1Params<T> p) {
 }
 // two workgroups per CU is what keeps HBM busy while the other workgroup computes: ask the register
 // allocator for (2 * threads / 256) waves per SIMD
+// ABL bit 6 (64): pair-fused first two sub-passes (engine.h; a production option, not an ablation)
 template <class T, class S, int F, bool FIRST, bool SPLIT, int ABL = 0>
 __global__ __launch_bounds__(F* S::TPF, (F * S::TPF >= 512 ? 4 : 2)) void k2_kernel(K2Params<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -293,6 +313,14 @@ template <class T, int NREG> struct HostExec {
     }
     void barrier() {}
     void relaunder() {}
+    // lanes l < 32 and l + 32 of each 64-thread wave exchange register slots (DevExec::pair_swap)
+    void pair_swap() {
+        if constexpr (NREG >= 32)
+            for (int t = 0; t < nt; ++t)
+                if ((t & 63) < 32 && t + 32 < nt)
+                    for (int m = 0; m < 4; ++m)
+                        for (int k = 0; k < 4; ++k) std::swap(regs[(size_t)(t + 32) * NREG + m * 8 + k], regs[(size_t)t * NREG + m * 8 + k + 4]);
+    }
 };
 template <class T, class S, int F, bool SPLIT, int STAGE> KernelEntry make_k1bs(int prec, const char* name) {
     KernelEntry e{};
@@ -519,6 +547,9 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
 // prefer different tilings
 #define MI_K2_FIRST(T, PREC, F, SPLIT, ...) reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, true, SPLIT>(PREC, "k2first<" #__VA_ARGS__ ">xF" #F))
 #define MI_K2_LATER(T, PREC, F, SPLIT, ...) reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, false, SPLIT>(PREC, "k2later<" #__VA_ARGS__ ">xF" #F))
+// pair-fused variants (engine.h pair_fusable schedules, Complex<float>)
+#define MI_K2P_FIRST(T, PREC, F, SPLIT, ...) reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, true, SPLIT, 64>(PREC, "k2first<" #__VA_ARGS__ ">xF" #F "p"))
+#define MI_K2P_LATER(T, PREC, F, SPLIT, ...) reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, false, SPLIT, 64>(PREC, "k2later<" #__VA_ARGS__ ">xF" #F "p"))
 #define MI_K2(T, PREC, F, SPLIT, ...)                                                                  \
     reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, true, SPLIT>(PREC, "k2first<" #__VA_ARGS__ ">xF" #F)); \
     reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, false, SPLIT>(PREC, "k2later<" #__VA_ARGS__ ">xF" #F))

@@ -403,3 +403,19 @@ def test_prime_radices_17_to_31(emu_planner, oracle, dtype):
             assert "dyn_k1" in fft.describe() or fft.describe().startswith("k1<"), (n, fft.describe())
             check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=2)
     assert "bluestein" in planner.plan_fft(4913, 0).describe()  # 17^3: three 17-point sub-passes need 289 threads per row
+
+
+def test_pair_fused_column_tiles(emu_planner, oracle):
+    """engine.h pair-fused sub-passes (first LDS exchange replaced by a lane-pair register exchange): the emulator's
+    executor swaps the register slots of threads t and t + 32 exactly as v_permlane32_swap does.  Selected here through the
+    tuning variant number (the emulator is a tuning build)."""
+    os.environ["MI355FFT_VARIANT"] = "12"
+    try:
+        planner = emu_planner(np.complex64)
+        for n in (1 << 18, 1 << 19, 1 << 20):
+            for d in (0, 1):
+                fft = planner.plan_fft(n, d)
+                assert "p" in fft.describe().split("->")[-1].split("xF")[-1], fft.describe()
+                check_fft_algorithm(fft, n, d, reference=oracle.plan(np.complex64, n, d), n=2)
+    finally:
+        del os.environ["MI355FFT_VARIANT"]

@@ -2,7 +2,7 @@
 """Interleaved A/B timing of kernel variants on ONE box in ONE process (boxes differ by several per cent, and so do
 back-to-back processes on one box: only interleaved rounds separate a 2 % effect from that noise).
 
-Arms are `lib[:VAR=value[,VAR=value...]]`: `lib` is "default" (rustfft_amd/lib/libmi355fft.so) or "tuning"
+Arms are `lib[:VAR=value[,VAR=value...]]`: `lib` is "default" (rustfft_amd/lib/libmi355fft.so), "min" (libmi355fft_tuning_min.so, `make tuning-min`: power-of-two kernels only) or "tuning"
 (libmi355fft_tuning.so, `make -C rustfft_amd/csrc tuning`); the MI355FFT_* variables are set while the arm's plans are
 created (tuning builds read them at plan creation, the shipped build reads none).
 Example: python tools/ab.py --log2n 20 --batch 1024 default tuning:MI355FFT_VARIANT=10
@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--oop", action="store_true", help="out-of-place calls x -> y (no plan-owned workspace: every arm touches the same two buffers)")
     ap.add_argument("--dist", default="pm1", choices=["pm1", "bench", "zero"], help="input distribution: U[-1,1) | bench.py's U[0,10) * 2^-100 | zeros")
     ap.add_argument("--shift-mib", type=float, default=0, help="allocate this many MiB first (moves the buffers' relative addresses)")
     args = ap.parse_args()
@@ -41,7 +42,7 @@ def main():
     arms = []
     for spec in args.arms:
         name, _, envs = spec.partition(":")
-        path = os.path.join(ROOT, "rustfft_amd", "lib", "libmi355fft.so" if name == "default" else "libmi355fft_tuning.so")
+        path = os.path.join(ROOT, "rustfft_amd", "lib", {"default": "libmi355fft.so", "tuning": "libmi355fft_tuning.so", "min": "libmi355fft_tuning_min.so"}[name])
         if path not in libs:
             libs[path] = _native.load(path)
         kv = dict(e.split("=") for e in envs.split(",") if e)
@@ -63,6 +64,7 @@ def main():
         else:
             x.zero_()
 
+    y2 = torch.empty_like(x) if args.oop else None
     torch.view_as_real(x).uniform_(-1.0, 1.0)
     x0 = x[:n].cpu().numpy()
     want = np.fft.fft(x0.astype(np.complex128))
@@ -80,8 +82,12 @@ def main():
             torch.cuda.synchronize()
             e0.record()
             for _ in range(args.iters):
-                a["fwd"].process(x)
-                a["inv"].process(x)
+                if args.oop:
+                    a["fwd"].process_outofplace_with_scratch(x, y2)
+                    a["inv"].process_outofplace_with_scratch(y2, x)
+                else:
+                    a["fwd"].process(x)
+                    a["inv"].process(x)
             e1.record()
             torch.cuda.synchronize()
             a["pair_ms"].append(e0.elapsed_time(e1) / args.iters)
