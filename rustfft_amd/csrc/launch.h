@@ -270,15 +270,12 @@ template <class T> KernelEntry make_dyn_k1(int prec) {
     e.launch = [](const void* params, long long grid, void* stream) {
         const DynK1Params<T>* p = (const DynK1Params<T>*)params;
         void* args[] = {const_cast<void*>(params)};
-        const void* fn = p->s.light == 1 ? (const void*)dyn_k1_kernel<T, 1> : p->s.light == 2 ? (const void*)dyn_k1_kernel<T, 2> : (const void*)dyn_k1_kernel<T, 0>;
-        (void)hipLaunchKernel(fn, dim3((unsigned)grid), dim3(p->s.f * p->s.tpf), args, (size_t)p->s.f * p->s.pitch * sizeof(cx<T>),
-                              (hipStream_t)stream);
+        // only the HEAVY radix set is planned as a plain transform (plan.cpp); the other sets serve the run-time scheduled Rader
+        (void)hipLaunchKernel((const void*)dyn_k1_kernel<T, 2>, dim3((unsigned)grid), dim3(p->s.f * p->s.tpf), args,
+                              (size_t)p->s.f * p->s.pitch * sizeof(cx<T>), (hipStream_t)stream);
     };
     e.prepare = []() -> int {
-        int a = (int)hipFuncSetAttribute((const void*)dyn_k1_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        int b = (int)hipFuncSetAttribute((const void*)dyn_k1_kernel<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        int c = (int)hipFuncSetAttribute((const void*)dyn_k1_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        return a ? a : b ? b : c;
+        return (int)hipFuncSetAttribute((const void*)dyn_k1_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     };
     return e;
 }
@@ -480,12 +477,7 @@ template <class T> KernelEntry make_dyn_k1(int prec) {
         std::vector<char> lds((size_t)p->s.f * p->s.pitch * sizeof(cx<T>) + 64, (char)0x5a);
         for (long long b = 0; b < grid; ++b) {
             HostExec<T, kDynEmaxHeavy> ex(p->s.f * p->s.tpf);
-            if (p->s.light == 1)
-                dyn_k1_body<T, kDynEmaxLight, 1>(ex, *p, b, lds.data());
-            else if (p->s.light == 2)
-                dyn_k1_body<T, kDynEmaxHeavy, 2>(ex, *p, b, lds.data());
-            else
-                dyn_k1_body<T, kDynEmax, 0>(ex, *p, b, lds.data());
+            dyn_k1_body<T, kDynEmaxHeavy, 2>(ex, *p, b, lds.data());
         }
     };
     e.prepare = []() -> int { return 0; };

@@ -46,6 +46,10 @@ template <class T> class Fft {
     Fft(std::size_t len, FftDirection direction) {
         detail::check(mi355fft_plan_create(len, (int)direction, detail::precision_of<T>::value, &plan_));
     }
+    // the host planner in charge (mi355fft_plan_create_ex): Recipe family, its own compute_twiddle, finished tables
+    Fft(std::size_t len, FftDirection direction, const mi355fft_plan_options& options) {
+        detail::check(mi355fft_plan_create_ex(len, (int)direction, detail::precision_of<T>::value, &options, &plan_));
+    }
     ~Fft() { mi355fft_plan_destroy(plan_); }
     Fft(const Fft&) = delete;
     Fft& operator=(const Fft&) = delete;
@@ -103,6 +107,11 @@ template <class T> class FftPlanner {
         auto fft = std::make_shared<const Fft<T>>(len, direction);
         cache_[key] = fft;
         return fft;
+    }
+    // not cached: the options belong to one call (src/plan.rs:134-188 Recipe -> algorithm; twiddles.rs:6-23 -> twiddle_fn)
+    std::shared_ptr<const Fft<T>> plan_fft_with(std::size_t len, FftDirection direction, mi355fft_plan_options options) {
+        options.struct_size = sizeof(mi355fft_plan_options);
+        return std::make_shared<const Fft<T>>(len, direction, options);
     }
     std::shared_ptr<const Fft<T>> plan_fft_forward(std::size_t len) { return plan_fft(len, FftDirection::Forward); }
     std::shared_ptr<const Fft<T>> plan_fft_inverse(std::size_t len) { return plan_fft(len, FftDirection::Inverse); }

@@ -68,6 +68,46 @@ template <class T> static int check_length(mi355::FftPlanner<T>& planner, size_t
     return 0;
 }
 
+// the host planner in charge (mi355fft_plan_create_ex): its own compute_twiddle (src/twiddles.rs:6-23 restated) and the
+// Recipe family it designed; the result must equal the default plan's bit for bit (same formula) / within tolerance
+static void host_twiddle(void* ctx, size_t index, size_t fft_len, double* re, double* im) {
+    ++*(size_t*)ctx;
+    const double angle = -2.0 * 3.14159265358979323846264338327950288 / (double)fft_len * (double)index;
+    *re = std::cos(angle);
+    *im = std::sin(angle);
+}
+static int check_host_planner() {
+    using C = std::complex<float>;
+    mi355::FftPlanner<float> planner;
+    for (size_t n : {1024, 1200, 65536}) {
+        size_t calls = 0;
+        mi355fft_plan_options o{};
+        o.twiddle_fn = host_twiddle;
+        o.twiddle_ctx = &calls;
+        auto hosted = planner.plan_fft_with(n, mi355::FftDirection::Forward, o);
+        auto plain = planner.plan_fft_forward(n);
+        std::vector<C> a(2 * n), b;
+        for (size_t i = 0; i < a.size(); ++i) a[i] = C((float)(i % 17), (float)(i % 5));
+        b = a;
+        hosted->process(a.data(), a.size());
+        plain->process(b.data(), b.size());
+        if (!calls || a != b) return std::printf("host twiddle plan differs at %zu (calls %zu)\n", n, calls), 1;
+    }
+    mi355fft_plan_options o{};
+    o.algorithm = MI355FFT_ALGO_BLUESTEIN;
+    if (planner.plan_fft_with(1024, mi355::FftDirection::Forward, o)->describe().find("bluestein") == std::string::npos)
+        return std::printf("ALGO_BLUESTEIN ignored\n"), 1;
+    o.algorithm = MI355FFT_ALGO_RADER;
+    try {
+        planner.plan_fft_with(1000, mi355::FftDirection::Forward, o);
+        return std::printf("ALGO_RADER accepted a composite length\n"), 1;
+    } catch (const mi355::FftPanic& e) {
+        if (e.status != MI355FFT_ERR_UNSUPPORTED) return std::printf("unexpected status %d\n", e.status), 1;
+    }
+    std::printf("ok host planner options\n");
+    return 0;
+}
+
 int main() {
     try {
         mi355::FftPlanner<float> pf;
@@ -78,6 +118,7 @@ int main() {
                 bad += check_length<float>(pf, n, dir);
                 bad += check_length<double>(pd, n, dir);
             }
+        bad += check_host_planner();
         return bad ? 1 : 0;
     } catch (const mi355::FftPanic& e) {
         std::printf("FftPanic(%d): %s\n", e.status, e.what());

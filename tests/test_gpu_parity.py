@@ -489,15 +489,26 @@ def test_single_kernel_above_4096(planners, oracle, dtype):
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_runtime_scheduled_kernels(planners, oracle, dtype):
-    """13-smooth lengths (run-time scheduled mixed radix, the RadixN analogue) and primes with 13-smooth p - 1
-    (run-time scheduled Rader) vs the oracle's planner choice, all four API modes."""
+    """Lengths the reference plans as RadixN / MixedRadix / RadersAlgorithm beyond the compiled single-kernel set: 13-smooth
+    lengths above one workgroup, lengths with a prime factor 17 .. 31 (run-time scheduled HEAVY kernel), and the Rader family
+    through the host-planner entry point, vs the oracle's planner choice, all four API modes."""
     planner = planners[np.dtype(dtype)]
-    for n in [4368, 4459, 4620, 5005]:
+    import rustfft_amd
+
+    for n in [4368, 4459, 4620, 5005, 20449, 45056]:  # 13-smooth above one workgroup: column-tile passes with 11 / 13 in the tile heights
+        for d in (0, 1):
+            fft = planner.plan_fft(n, d)
+            assert "k2gfirst" in fft.describe(), (n, fft.describe())
+            check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=3)
+    for n in [4352, 5168, 6448]:  # a prime factor 17 .. 31 above the compiled set: the run-time scheduled HEAVY kernel
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
             assert "dyn_k1" in fft.describe(), (n, fft.describe())
-            check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=5 if n < 512 else 3)
-    import rustfft_amd
+            check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=3)
+    for n in [1088, 3553]:  # ... which a host planner can also ask for below 4096 (AUTO prefers compiled schedules / Bluestein there)
+        fft = planner.plan_fft_with(n, 0, algorithm=rustfft_amd.ALGO_MIXED_RADIX)
+        assert "dyn_k1" in fft.describe() or fft.describe().startswith("k1<"), (n, fft.describe())
+        check_fft_algorithm(fft, n, 0, reference=oracle.plan(dtype, n, 0), n=3)
 
     # run-time scheduled Rader: what a host planner gets when its Recipe says RadersAlgorithm (mi355fft_plan_create_ex,
     # MI355FFT_ALGO_RADER) for a prime without a compiled body; AUTO plans these primes through other kernels
@@ -568,3 +579,31 @@ def test_cpp_host_mirror(planners):
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
     assert r.stdout.count("ok n=") == 40
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_every_prime_below_1000_and_prime_radices(planners, oracle, dtype):
+    """Every prime < 1000 through the planner's own choice (butterflies 2 .. 31, compiled Rader bodies where p - 1 is
+    13-smooth, Bluestein elsewhere -- raders_algorithm.rs:302-322 and bluesteins_algorithm.rs:210-215 test the same families)
+    and a spread of lengths with a prime factor 17 .. 31 (butterflies.rs:6414-6433), against the oracle."""
+    planner = planners[np.dtype(dtype)]
+    primes = [p for p in range(2, 1000) if all(p % q for q in range(2, int(p**0.5) + 1))]
+    families = set()
+    for p in primes:
+        for d in (0, 1):
+            fft = planner.plan_fft(p, d)
+            families.add(fft.describe().split("<")[0])
+            x = random_signal(3 * p, dtype)
+            y = x.copy()
+            fft.process(y)
+            want = x.copy()
+            oracle.plan(dtype, p, d).process(want)
+            assert compare_vectors(want, y), (p, d, fft.describe())
+            assert rel_l2(y, numpy_fft(x, p, d == 1)) < REL[np.dtype(dtype)], (p, d)
+    assert {"k1", "rader", "bluestein"} <= families, families
+    limit = 2048 if dtype == np.complex64 else 1024
+    for n in (34, 289, 323, 437, 527, 899, 961, 992, 1023, 1088, 1411, 1734, 2047):
+        fft = planner.plan_fft(n, 0)
+        if n <= limit:
+            assert fft.describe().startswith("k1<%d," % n), (n, fft.describe())
+        check_fft_algorithm(fft, n, 0, reference=oracle.plan(dtype, n, 0), n=3)
