@@ -98,6 +98,23 @@ template <bool LIN, int N_, int TPF_, int... Rs> struct SchedImpl {
 template <int N_, int TPF_, int... Rs> struct Sched : SchedImpl<false, N_, TPF_, Rs...> {};
 template <int N_, int TPF_, int... Rs> struct SchedL : SchedImpl<true, N_, TPF_, Rs...> {};
 
+// The same schedule with its sub-passes in REVERSE order.  The last sub-pass of a transform (radix R) leaves butterfly b's
+// outputs y[b + k N/R] in a thread's registers -- exactly the inputs x[b + k N/R] of a FIRST sub-pass of radix R with the
+// same thread layout.  So a transform that follows another one element-wise (Bluestein's two inner transforms, with the
+// spectrum multiply in between) can run the reversed schedule and pick its inputs up from the registers: no LDS staging
+// of the intermediate spectrum, one exchange and one barrier fewer per row.
+template <class Acc, int... Rs> struct rev_pack;
+template <template <int, int, int...> class TT, int N_, int TPF_, int... Acc, int R0, int... Rs>
+struct rev_pack<TT<N_, TPF_, Acc...>, R0, Rs...> : rev_pack<TT<N_, TPF_, R0, Acc...>, Rs...> {};
+template <template <int, int, int...> class TT, int N_, int TPF_, int... Acc> struct rev_pack<TT<N_, TPF_, Acc...>> {
+    using type = TT<N_, TPF_, Acc...>;
+};
+template <class S> struct reversed_sched;
+template <int N_, int TPF_, int... Rs> struct reversed_sched<Sched<N_, TPF_, Rs...>> : rev_pack<Sched<N_, TPF_>, Rs...> {};
+template <int N_, int TPF_, int... Rs> struct reversed_sched<SchedL<N_, TPF_, Rs...>> : rev_pack<SchedL<N_, TPF_>, Rs...> {};
+// destination marker: the last sub-pass leaves its outputs in the register array (slot m R + k = output k of butterfly m)
+struct KeepInRegs {};
+
 // Two layouts for power-of-two schedules:
 //  * swizzle (threads holding <= 16 values): XOR the run index of the scatter into the bank bits.  Sub-pass x scatters
 //    runs of s_x consecutive elements at stride s_x R_x; the XOR puts the runs of one wave on distinct banks, and any
@@ -358,7 +375,8 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
         int f, u;
         map_tid<MP, F, S::TPF>(tid, f, u);
         if constexpr (!(ABL & 4)) compute_pass<T, S, P, TWREG>(v, u, tw);
-        if constexpr (LAST) {
+        if constexpr (LAST && std::is_same<DST, KeepInRegs>::value) {
+        } else if constexpr (LAST) {
             static_for<0, BPT>([&](auto M_) {
                 constexpr int m = M_;
                 const int b = u + m * S::TPF;

@@ -302,19 +302,40 @@ MI_HD void k2g_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
 }
 
 // ---- Bluestein: any length n <= (M + 1) / 2 through two length-M workgroup transforms ---------------------
+// The second transform runs the REVERSED schedule (engine.h reversed_sched): the first one leaves X[b + k M/R] in the
+// registers of the thread that needs exactly those values as inputs of its first radix-R butterflies, so the spectrum
+// multiply conj(X bf) happens in registers and the intermediate spectrum never goes through LDS (round 1 staged it in a
+// natural-order LDS row: one more write + read of M elements and one more barrier per row).
+template <class T, class S2> struct BluesteinRegSrc {
+    static constexpr bool kLoadsAll = true;
+    const cx<T>* MI_RESTRICT bf;
+    template <class SS> MI_HD void load_all(int, int u, cx<T>* v) const {
+        static_assert(std::is_same<SS, S2>::value, "source of the reversed schedule");
+        constexpr int R = S2::R[0], NB = S2::nb(0), BPT = S2::bpt(0);
+        static_for<0, BPT>([&](auto M_) {
+            constexpr int m = M_;
+            const int b = u + m * S2::TPF;
+            if ((m + 1) * S2::TPF <= NB || b < NB) {
+                static_for<0, R>([&](auto K_) {
+                    constexpr int k = K_;
+                    v[m * R + k] = cconj(v[m * R + k] * bf[(unsigned)(b + k * NB)]);
+                });
+            }
+        });
+    }
+};
 template <class T, class S, int F, class X>
 MI_HD void bluestein_body(X& ex, const BluesteinParams<T>& p, long long block, void* lds) {
-    constexpr int M = S::N, PITCH = S::pitch();
+    using S2 = typename reversed_sched<S>::type;
+    static_assert(S2::R[0] == S::R[S::NP - 1] && S2::nb(0) == S::nb(S::NP - 1) && S2::bpt(0) == S::bpt(S::NP - 1), "register hand-over");
     const long long fft0 = block * F;
     // uniform row base + 32-bit offsets: one address register per access instead of a 64-bit pair
     const cx<T>* MI_RESTRICT in = p.in + fft0 * p.n;
     cx<T>* MI_RESTRICT out = p.out + fft0 * p.n;
     const cx<T>* MI_RESTRICT chirp = p.chirp;
-    const cx<T>* MI_RESTRICT bf = p.bf;
     const int rows = (int)((p.batch - fft0) < F ? (p.batch - fft0) : F);
     const int n = p.n;
     const T sgn = p.sgn;
-    cx<T>* work = (cx<T>*)lds;  // natural-order spectrum; reuses the exchange buffer once the first transform is done
     auto src1 = [=](int f, int i) -> cx<T> {
         if (f < rows && i < n) {
             cx<T> x = in[(unsigned)(f * n + i)];
@@ -323,12 +344,8 @@ MI_HD void bluestein_body(X& ex, const BluesteinParams<T>& p, long long block, v
         }
         return cx<T>{0, 0};
     };
-    auto dst1 = [=](int f, int j, cx<T> v) { work[f * PITCH + j] = cconj(v * bf[(unsigned)j]); };
-    constexpr bool BS_STAGE = false;
-    constexpr int TW0 = BS_STAGE ? S::emax() : -1;  // staging registers for the next sub-pass's twiddles (engine.h TWSTAGE)
-    wg_fft<T, S, F, MAP_EF, MAP_EF, false, false, 1, 0, TW0, BS_STAGE>(ex, lds, p.tw, elem_src(src1), dst1);
-    ex.barrier();
-    auto src2 = [=](int f, int i) -> cx<T> { return work[f * PITCH + i]; };
+    wg_fft<T, S, F, MAP_EF, MAP_EF, false>(ex, lds, p.tw, elem_src(src1), KeepInRegs{});
+    // (the engine's barrier after the last gather of the first transform already orders it before the second one's scatters)
     auto dst2 = [=](int f, int j, cx<T> v) {
         if (f < rows && j < n) {
             cx<T> y = cconj(v) * chirp[(unsigned)j];
@@ -336,8 +353,7 @@ MI_HD void bluestein_body(X& ex, const BluesteinParams<T>& p, long long block, v
             out[(unsigned)(f * n + j)] = y;
         }
     };
-    wg_fft<T, S, F, MAP_EF, MAP_EF, false, true, 1, 0, TW0, BS_STAGE>(ex, lds, p.tw, elem_src(src2), dst2);
-    (void)M;
+    wg_fft<T, S2, F, MAP_EF, MAP_EF, false>(ex, lds, p.tw2, BluesteinRegSrc<T, S2>{p.bf}, dst2);
 }
 
 // ---- run-time scheduled batched transform (13-smooth lengths) ------------------------------------------------

@@ -44,6 +44,7 @@ template <class T> struct BluesteinParams {
     const cx<T>* in;
     cx<T>* out;
     const cx<T>* tw;     // sub-pass twiddles of the length-M transform
+    const cx<T>* tw2;    // the same for the REVERSED schedule (one-kernel Bluestein: second transform)
     const cx<T>* chirp;  // n entries, w[i] = twiddle(i^2 mod 2n, 2n), forward (src/twiddles.rs:25-57)
     const cx<T>* bf;     // M entries, FFT_M of the mirrored conjugate chirp / M (bluesteins_algorithm.rs:63-87)
     long long batch;

@@ -170,7 +170,10 @@ template <class T> KernelEntry make_pointwise(int prec) {
     e.prepare = []() -> int { return 0; };
     return e;
 }
-template <class T, class S, int F> constexpr size_t bluestein_lds() { return (size_t)F * S::pitch() * sizeof(cx<T>); }
+template <class T, class S, int F> constexpr size_t bluestein_lds() {
+    using S2 = typename reversed_sched<S>::type;  // the second transform runs the reversed schedule (kernels.h bluestein_body)
+    return (size_t)F * (S::pitch() > S2::pitch() ? S::pitch() : S2::pitch()) * sizeof(cx<T>);
+}
 template <class T, class S, int F, int MODE> constexpr size_t rader_lds() {
     return (size_t)(MODE >= 2 ? 1 : F) * (S::pitch() + (MODE >= 1 ? 0 : S::N + 1)) * sizeof(cx<T>);
 }
@@ -394,7 +397,10 @@ template <class T> KernelEntry make_pointwise(int prec) {
     e.prepare = []() -> int { return 0; };
     return e;
 }
-template <class T, class S, int F> constexpr size_t bluestein_lds() { return (size_t)F * S::pitch() * sizeof(cx<T>); }
+template <class T, class S, int F> constexpr size_t bluestein_lds() {
+    using S2 = typename reversed_sched<S>::type;  // the second transform runs the reversed schedule (kernels.h bluestein_body)
+    return (size_t)F * (S::pitch() > S2::pitch() ? S::pitch() : S2::pitch()) * sizeof(cx<T>);
+}
 template <class T, class S, int F, int MODE> constexpr size_t rader_lds() {
     return (size_t)(MODE >= 2 ? 1 : F) * (S::pitch() + (MODE >= 1 ? 0 : S::N + 1)) * sizeof(cx<T>);
 }

@@ -835,6 +835,10 @@ template <class T> static int build_plan_t(Plan& plan) {
         pd.k = bc.k1;
         pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(*bc.k1), &rc);
         if (rc) return rc;
+        KernelEntry rev = *bc.k1;  // the second transform runs the sub-passes in reverse order (kernels.h bluestein_body)
+        for (int i = 0; i < rev.np; ++i) rev.radix[i] = bc.k1->radix[rev.np - 1 - i];
+        pd.d_tw2 = upload<T>(plan, build_subpass_twiddles<T>(rev), &rc);
+        if (rc) return rc;
         if ((rc = bluestein_tables<T>(plan, bc.M, &pd.d_aux1, &pd.d_aux2))) return rc;
         plan.passes.push_back(pd);
         return MI355FFT_OK;
@@ -1031,6 +1035,7 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         p.in = (const cx<T>*)in;
         p.out = (cx<T>*)out;
         p.tw = (const cx<T>*)pd.d_tw;
+        p.tw2 = (const cx<T>*)pd.d_tw2;
         p.chirp = (const cx<T>*)pd.d_aux1;
         p.bf = (const cx<T>*)pd.d_aux2;
         p.batch = (long long)batch;

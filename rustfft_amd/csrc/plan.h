@@ -17,6 +17,7 @@ enum PlanKind { PLAN_TRIVIAL = 0, PLAN_SINGLE = 1, PLAN_MACRO = 2, PLAN_BLUESTEI
 struct PassDesc {
     const KernelEntry* k;
     void* d_tw;   // sub-pass twiddles of the workgroup transform
+    void* d_tw2;  // one-kernel Bluestein: the same for the reversed schedule of the second transform
     void* d_tlo;  // two-level inter-pass twiddle tables (macro passes after the first)
     void* d_thi;
     int hshift, lmask;

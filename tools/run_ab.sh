@@ -1,4 +1,3 @@
 mkdir -p gpurun_out/r2
-python tools/ab.py --oop --log2n 20 --batch 1024 min min:MI355FFT_VARIANT=12 min 2>&1 | grep arm | tee gpurun_out/r2/ab6.jsonl | cut -c1-300
-python tools/ab.py --oop --log2n 18 --batch 4096 min min:MI355FFT_VARIANT=12 min 2>&1 | grep arm | tee -a gpurun_out/r2/ab6.jsonl | cut -c1-300
-python tools/ab.py --oop --log2n 19 --batch 2048 min min:MI355FFT_VARIANT=12 2>&1 | grep arm | tee -a gpurun_out/r2/ab6.jsonl | cut -c1-300
+python tools/sweep.py --dtype f32 --sizes 7919,19,31,127,251,509,719,1019,1531,2039,3079,4093 --check --bytes 1 2>/dev/null | cut -c1-250 | tee gpurun_out/r2/bs_regs_f32.jsonl
+python tools/sweep.py --dtype f64 --sizes 19,127,719,1019,2039,4093 --check --bytes 1 2>/dev/null | cut -c1-250 | tee gpurun_out/r2/bs_regs_f64.jsonl
