@@ -11,6 +11,12 @@ void register_k1_f32(std::vector<KernelEntry>& reg) {
     MI_K1(float, 32, 1, true, 16384, 512, 16, 32, 32);
     MI_K1(float, 32, 1, true, 32768, 1024, 32, 32, 32);
     MI_K1V(3, float, 32, 1, false, 8192, 512, 16, 8, 8, 8);
+    // tuning: split exchange for the LDS-bound 2^10 .. 2^12 kernels (half the LDS per workgroup: six instead of four per CU)
+    MI_K1V(20, float, 32, 4, true, 1024, 64, 16, 16, 4);
+    MI_K1V(20, float, 32, 2, true, 2048, 128, 16, 16, 8);
+    MI_K1V(20, float, 32, 1, true, 4096, 256, 16, 16, 16);
+    MI_K1V(21, float, 32, 2, false, 1024, 64, 16, 16, 4);
+    MI_K1V(21, float, 32, 1, false, 2048, 128, 16, 16, 8);
     // two-kernel Bluestein for 4096 < n <= 16384 (padded lengths 3 * 2^12, 2^14, 3 * 2^13, 2^15)
     MI_BS2(float, 32, 1, true, 12288, 512, 32, 24, 16);
     MI_BS2(float, 32, 1, true, 16384, 512, 16, 32, 32);

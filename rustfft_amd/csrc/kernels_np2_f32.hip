@@ -12,11 +12,21 @@ void register_np2_f32(std::vector<KernelEntry>& reg) {
     // Rader 1009: eight rows per workgroup, one after another, every per-thread table in registers (kernels.h
     // rader_rows_body).  Measured on MI355X (2 GiB of rows): 3.0 TB/s, against 2.3 (one row per workgroup, staged rows,
     // variant 1), 2.1 (variant 2: scatter on load, 128 threads) and 2.4 (variant 4: no prefetch of the next row).
-    MI_RADER(float, 32, 8, 2, 1008, 144, 16, 9, 7);
+    // (round 2, interleaved A/B of seven schedules of 1008: 14 x 9 x 8 on 126 threads = two full waves: 3.36 TB/s against 3.22)
+    MI_RADER(float, 32, 8, 2, 1008, 126, 14, 9, 8);
+    MI_RADERV(37, float, 32, 8, 2, 1008, 144, 16, 9, 7);
     MI_RADERV(1, float, 32, 1, 0, 1008, 144, 16, 9, 7);
     MI_RADERV(2, float, 32, 1, 1, 1008, 128, 16, 9, 7);
     MI_RADERV(3, float, 32, 32, 2, 1008, 144, 16, 9, 7);
     MI_RADERV(4, float, 32, 8, 3, 1008, 144, 16, 9, 7);
+    // tuning: other schedules of the inner length 1008 = 2^4 3^2 7 in the rows loop
+    MI_RADERV(30, float, 32, 8, 2, 1008, 126, 8, 9, 14);
+    MI_RADERV(31, float, 32, 8, 2, 1008, 126, 14, 9, 8);
+    MI_RADERV(32, float, 32, 8, 2, 1008, 84, 12, 12, 7);
+    MI_RADERV(33, float, 32, 8, 2, 1008, 112, 16, 9, 7);
+    MI_RADERV(34, float, 32, 8, 2, 1008, 126, 16, 9, 7);
+    MI_RADERV(35, float, 32, 16, 2, 1008, 144, 16, 9, 7);
+    MI_RADERV(36, float, 32, 4, 2, 1008, 144, 16, 9, 7);
     MI_BS_LIST(float, 32);
     MI_BS(float, 32, 2, 512, 64, 8, 8, 8);
     MI_BS(float, 32, 1, 1024, 64, 16, 16, 4);    // one wave per row: 1.68 TB/s against 1.55 with four rows per workgroup

@@ -142,11 +142,13 @@ __global__ __launch_bounds__(F* S::TPF) void bluestein_kernel(BluesteinParams<T>
     bluestein_body<T, S, F>(ex, p, (long long)blockIdx.x, smem);
 }
 template <class T, class S, int F, int MODE>
-__global__ __launch_bounds__((MODE >= 2 ? 1 : F) * S::TPF, (MODE == 2 ? (sizeof(T) == 4 ? 3 : 2) : MODE == 3 ? (sizeof(T) == 4 ? 4 : 2) : 1)) void rader_kernel(RaderParams<T> p) {
+// MODE 2: rows loop with next-row prefetch (>= 3 waves per SIMD in f32); MODE 3: without the prefetch; MODE 4: as MODE 2 for the
+// larger primes whose per-thread tables need up to 256 VGPRs (two waves per SIMD)
+__global__ __launch_bounds__((MODE >= 2 ? 1 : F) * S::TPF, (MODE == 2 ? (sizeof(T) == 4 ? 3 : 2) : MODE == 3 ? (sizeof(T) == 4 ? 4 : 2) : MODE == 4 ? 2 : 1)) void rader_kernel(RaderParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if constexpr (MODE >= 2) {  // F = rows pushed through one workgroup one after another
         DevExecLoop<T, RaderRows<S>::NREG> ex;
-        rader_rows_body<T, S, F, MODE == 2>(ex, p, (long long)blockIdx.x, smem);
+        rader_rows_body<T, S, F, MODE == 2 || MODE == 4>(ex, p, (long long)blockIdx.x, smem);
     } else {
         DevExec<T, regs_needed<S, false>()> ex;
         rader_body<T, S, F, MODE>(ex, p, (long long)blockIdx.x, smem);
@@ -441,7 +443,7 @@ template <class T, class S, int F, int MODE> KernelEntry make_rader(int prec, co
         for (long long b = 0; b < grid; ++b) {
             if constexpr (MODE >= 2) {
                 HostExec<T, RaderRows<S>::NREG> ex(S::TPF);
-                rader_rows_body<T, S, F, MODE == 2>(ex, *(const RaderParams<T>*)params, b, lds.data());
+                rader_rows_body<T, S, F, MODE == 2 || MODE == 4>(ex, *(const RaderParams<T>*)params, b, lds.data());
             } else {
                 HostExec<T, regs_needed<S, false>()> ex(F * S::TPF);
                 rader_body<T, S, F, MODE>(ex, *(const RaderParams<T>*)params, b, lds.data());

@@ -32,10 +32,10 @@ void ensure_registry() {
         register_k1_f64(r);
         register_k2_f32(r);
         register_k2_f64(r);
-#if defined(MI355_MINIMAL)  // `make tuning-min`: only the power-of-two kernels (kernel experiments that need a one-minute build)
+        register_np2_f32(r);
+#if defined(MI355_MINIMAL)  // `make tuning-min`: power-of-two kernels + the f32 Rader / Bluestein unit (kernel experiments that need a one-minute build)
         return;
 #endif
-        register_np2_f32(r);
         register_np2_f64(r);
         register_k2g_f32_0(r);
         register_k2g_f32_1(r);

@@ -1,3 +1,2 @@
 mkdir -p gpurun_out/r2
-python tools/sweep.py --dtype f32 --sizes 7919,19,31,127,251,509,719,1019,1531,2039,3079,4093 --check --bytes 1 2>/dev/null | cut -c1-250 | tee gpurun_out/r2/bs_regs_f32.jsonl
-python tools/sweep.py --dtype f64 --sizes 19,127,719,1019,2039,4093 --check --bytes 1 2>/dev/null | cut -c1-250 | tee gpurun_out/r2/bs_regs_f64.jsonl
+python tools/ab.py --oop --n 1009 --batch 1048576 --rounds 5 min min:MI355FFT_VARIANT=30 min:MI355FFT_VARIANT=31 min:MI355FFT_VARIANT=32 min:MI355FFT_VARIANT=33 min:MI355FFT_VARIANT=34 min:MI355FFT_VARIANT=35 min:MI355FFT_VARIANT=36 2>&1 | grep arm | cut -c1-260 | tee gpurun_out/r2/ab8.jsonl
