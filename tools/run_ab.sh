@@ -1,2 +1,8 @@
 mkdir -p gpurun_out/r2
-python tools/ab.py --oop --n 1009 --batch 1048576 --rounds 5 min min:MI355FFT_VARIANT=30 min:MI355FFT_VARIANT=31 min:MI355FFT_VARIANT=32 min:MI355FFT_VARIANT=33 min:MI355FFT_VARIANT=34 min:MI355FFT_VARIANT=35 min:MI355FFT_VARIANT=36 2>&1 | grep arm | cut -c1-260 | tee gpurun_out/r2/ab8.jsonl
+python tools/prime_sweep.py > gpurun_out/r2/primes2.json 2>/dev/null
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/r2/primes2.json')); print(json.dumps(d['summary']))
+r=[x for x in d['primes'] if x[2]=='rader']; print(sorted(r,key=lambda x:x[1])[:8]); print(sorted(r,key=lambda x:-x[1])[:8])
+PY
+python bench.py --config c4 --no-pmc --no-cpu-baseline 2>/dev/null | cut -c1-900
