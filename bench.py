@@ -398,6 +398,22 @@ def main():
     }
     if check["roundtrip_rel_l2"] > 5e-6 or check["parseval_max_rel_err"] > 1e-4 or not finite:
         out["check"]["FAILED"] = True
+    if world > 1 and args.edges:
+        # SURVEY section 8(e) edges, timed apart from the compute path: a batch that lives on rank 0 goes out with grouped
+        # send / recv, every rank transforms its rows, the rows come back (64 transforms per rank keep the root's buffer small)
+        from rustfft_amd import sharding
+
+        eb = 64 * world
+        full = None
+        if rank == 0:
+            full = torch.empty(eb * n, dtype=torch.complex64, device="cuda")
+            fill_blocks(torch, full, eb, n, seed_gen())
+        _, t = sharding.process_from_root(fwd, full, n, eb, dist, root=0, device="cuda", dtype=torch.complex64, sync=torch.cuda.synchronize)
+        gib = eb * n * 8 / 2**30
+        out["edges"] = {"workload": f"{eb} transforms of 2^{args.log2n} on rank 0 ({gib:.1f} GiB) -> {world} ranks -> rank 0",
+                        **{k: reduce_max(v, dist, device="cuda") for k, v in t.items()},
+                        "scatter_GBps": gib * 2**30 * (world - 1) / world / max(t["scatter_s"], 1e-9) / 1e9}
+        del full
     if world > 1 and not args.no_config5:
         del data
         torch.cuda.empty_cache()

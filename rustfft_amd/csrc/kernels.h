@@ -24,8 +24,8 @@ template <class T, class S, int F, bool SPLIT, int ABL = 0, class X>
 MI_HD void k1_body(X& ex, const K1Params<T>& p, long long block, void* lds) {
     const long long fft0 = block * F;
     // workgroup-uniform base + 32-bit element offsets (F * N < 2^31): one address VGPR per access
-    const cx<T>* MI_RESTRICT in = p.in + fft0 * S::N;
-    cx<T>* MI_RESTRICT out = p.out + fft0 * S::N;
+    const cx<T>* in = p.in + fft0 * S::N;
+    cx<T>* out = p.out + fft0 * S::N;
     const int rows = (int)((p.batch - fft0) < F ? (p.batch - fft0) : F);
     const T sgn = p.sgn;
     auto src = [=](int f, int i) -> cx<T> {
@@ -61,8 +61,8 @@ MI_HD void k1bs_body(X& ex, const BluesteinParams<T>& p, long long block, void* 
     constexpr unsigned M = S::N;
     const long long fft0 = block * F;
     const unsigned n = (unsigned)p.n;
-    const cx<T>* MI_RESTRICT in = p.in + fft0 * (STAGE == 1 ? (long long)n : (long long)M);
-    cx<T>* MI_RESTRICT out = p.out + fft0 * (STAGE == 1 ? (long long)M : (long long)n);
+    const cx<T>* in = p.in + fft0 * (STAGE == 1 ? (long long)n : (long long)M);
+    cx<T>* out = p.out + fft0 * (STAGE == 1 ? (long long)M : (long long)n);
     const cx<T>* MI_RESTRICT chirp = p.chirp;
     const cx<T>* MI_RESTRICT bf = p.bf;
     const int rows = (int)((p.batch - fft0) < F ? (p.batch - fft0) : F);
@@ -108,7 +108,7 @@ constexpr int k2_pitch_mod(int f) { return f < 32 ? 32 / f : 1; }
 // 4.4 - 4.8; divergent 8-byte gathers cost the L1 one cycle per lane, the row segments one per 16 lanes.)
 template <class T, bool FIRST, int ABL = 0> struct K2Src {
     static constexpr bool kLoadsAll = true;
-    const cx<T>* MI_RESTRICT in;
+    const cx<T>* in;  // no restrict: the in-place last pass reads and writes the caller's buffer
     unsigned M, b0, bmod0;
     T sgn_in;
     const cx<T>* MI_RESTRICT tlo;
@@ -179,8 +179,8 @@ MI_HD void k2_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     const long long g = block >> p.tiles_shift;
     const unsigned tile = (unsigned)(block & ((1LL << p.tiles_shift) - 1));
     const unsigned b0 = tile * (unsigned)F;
-    const cx<T>* MI_RESTRICT in = p.in + g * p.n;
-    cx<T>* MI_RESTRICT out = p.out + g * p.n;
+    const cx<T>* in = p.in + g * p.n;
+    cx<T>* out = p.out + g * p.n;
     const unsigned M = (unsigned)p.m, s32 = (unsigned)p.s;
     const T sgn_out = p.sgn_out;
     // a tile never straddles a multiple of S (F | S whenever S > 1), so B div S is tile-uniform
@@ -210,7 +210,7 @@ MI_HD void k2_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
 // multiplies by the chirp and zero-pads on the fly; 2 = the last pass stores conj(X * bf); 3 = the last pass stores
 // conj(X) * chirp, truncated to n, into the caller's rows.  0 = plain pass.
 template <class T, bool FIRST, int FUSE = 0> struct K2gSrc {
-    const cx<T>* MI_RESTRICT in;
+    const cx<T>* in;
     unsigned M, S, b0;
     T sgn_in;
     const cx<T>* MI_RESTRICT tlo;
@@ -268,8 +268,8 @@ MI_HD void k2g_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     constexpr int R = S::N;
     const long long g = block / p.tiles_per_fft;
     const unsigned b0 = (unsigned)(block % p.tiles_per_fft) * (unsigned)F;
-    const cx<T>* MI_RESTRICT in = p.in + g * (FUSE == 1 ? p.n_io : p.n);
-    cx<T>* MI_RESTRICT out = p.out + g * (FUSE == 3 ? p.n_io : p.n);
+    const cx<T>* in = p.in + g * (FUSE == 1 ? p.n_io : p.n);
+    cx<T>* out = p.out + g * (FUSE == 3 ? p.n_io : p.n);
     const unsigned M = (unsigned)p.m, Sg = (unsigned)p.s;
     const T sgn_out = p.sgn_out;
     const cx<T>* MI_RESTRICT tab = p.tab;
@@ -330,8 +330,8 @@ MI_HD void bluestein_body(X& ex, const BluesteinParams<T>& p, long long block, v
     static_assert(S2::R[0] == S::R[S::NP - 1] && S2::nb(0) == S::nb(S::NP - 1) && S2::bpt(0) == S::bpt(S::NP - 1), "register hand-over");
     const long long fft0 = block * F;
     // uniform row base + 32-bit offsets: one address register per access instead of a 64-bit pair
-    const cx<T>* MI_RESTRICT in = p.in + fft0 * p.n;
-    cx<T>* MI_RESTRICT out = p.out + fft0 * p.n;
+    const cx<T>* in = p.in + fft0 * p.n;
+    cx<T>* out = p.out + fft0 * p.n;
     const cx<T>* MI_RESTRICT chirp = p.chirp;
     const int rows = (int)((p.batch - fft0) < F ? (p.batch - fft0) : F);
     const int n = p.n;
@@ -362,8 +362,8 @@ MI_HD void dyn_k1_body(X& ex, const DynK1Params<T>& p, long long block, void* ld
     const DynSched& s = p.s;
     const long long fft0 = block * s.f;
     const int n = s.n;
-    const cx<T>* MI_RESTRICT in = p.in + fft0 * n;
-    cx<T>* MI_RESTRICT out = p.out + fft0 * n;
+    const cx<T>* in = p.in + fft0 * n;
+    cx<T>* out = p.out + fft0 * n;
     const int rows = (int)((p.batch - fft0) < s.f ? (p.batch - fft0) : s.f);
     const T sgn = p.sgn;
     auto src = [=](int f, int i) -> cx<T> {
@@ -389,8 +389,8 @@ MI_HD void dyn_rader_body(X& ex, const DynRaderParams<T>& p, long long block, vo
     const DynSched& s = p.s;
     const int M = s.n, P = s.n + 1, PITCH = s.pitch, F = s.f, NT = s.f * s.tpf;
     const long long fft0 = block * F;
-    const cx<T>* MI_RESTRICT in = p.in;
-    cx<T>* MI_RESTRICT out = p.out;
+    const cx<T>* in = p.in;
+    cx<T>* out = p.out;
     const cx<T>* MI_RESTRICT dtab = p.d;
     const int* MI_RESTRICT perm_in = p.perm_in;
     const int* MI_RESTRICT perm_out = p.perm_out;
@@ -469,8 +469,8 @@ template <class T, class S, int F, int MODE, class X>
 MI_HD void rader_body(X& ex, const RaderParams<T>& p, long long block, void* lds) {
     constexpr int M = S::N, P = S::N + 1, PITCH = S::pitch(), NT = F * S::TPF;
     const long long fft0 = block * F;
-    const cx<T>* MI_RESTRICT in = p.in;
-    cx<T>* MI_RESTRICT out = p.out;
+    const cx<T>* in = p.in;
+    cx<T>* out = p.out;
     const cx<T>* MI_RESTRICT dtab = p.d;
     const int* MI_RESTRICT perm_in = p.perm_in;
     const int* MI_RESTRICT perm_out = p.perm_out;
@@ -594,8 +594,8 @@ MI_HD void rader_rows_body(X& ex, const RaderParams<T>& p, long long block, void
     using L = RaderRows<S>;
     constexpr int P = L::P, PITCH = S::pitch(), NT = L::NT, NL = L::NL, XS = L::XS;
     static_assert(XS + 1 < PITCH && P <= PITCH, "row pitch must leave two spare slots");
-    const cx<T>* MI_RESTRICT in = p.in;
-    cx<T>* MI_RESTRICT out = p.out;
+    const cx<T>* in = p.in;
+    cx<T>* out = p.out;
     const T sgn = p.sgn;
     cx<T>* work = (cx<T>*)lds;
     const long long row0 = block * ROWS;

@@ -991,6 +991,9 @@ size_t Plan::trim_workspaces() {
 }
 
 // ---- execution -------------------------------------------------------------------------------------------
+// A grid above the HIP limit cannot be reached with buffers that fit 288 GB (the smallest workgroup moves 4 KiB), but a
+// truncated launch would transform a subset of the rows silently: checked before every launch.
+static const long long kMaxGrid = 0x7fffffffLL;
 template <class T>
 static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, size_t batch, void* stream, Tracer* tr) {
     const PassDesc& pd = plan.passes[pi];
@@ -1006,6 +1009,7 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         p.batch = (long long)batch;
         p.sgn = inverse ? (T)-1 : (T)1;
         grid = (long long)((batch + k.f - 1) / k.f);
+        if (grid > kMaxGrid) return MI355FFT_ERR_INVALID_ARG;
         k.launch(&p, grid, stream);
     } else if (k.kind == KIND_DYN_K1) {
         DynK1Params<T> p{};
@@ -1016,6 +1020,7 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         p.sgn = inverse ? (T)-1 : (T)1;
         p.s = pd.dyn;
         grid = (long long)((batch + pd.dyn.f - 1) / pd.dyn.f);
+        if (grid > kMaxGrid) return MI355FFT_ERR_INVALID_ARG;
         k.launch(&p, grid, stream);
     } else if (k.kind == KIND_DYN_RADER) {
         DynRaderParams<T> p{};
@@ -1029,6 +1034,7 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         p.sgn = inverse ? (T)-1 : (T)1;
         p.s = pd.dyn;
         grid = (long long)((batch + pd.dyn.f - 1) / pd.dyn.f);
+        if (grid > kMaxGrid) return MI355FFT_ERR_INVALID_ARG;
         k.launch(&p, grid, stream);
     } else if (k.kind == KIND_BLUESTEIN || k.kind == KIND_BS2_FIRST || k.kind == KIND_BS2_SECOND) {
         BluesteinParams<T> p{};
@@ -1042,6 +1048,7 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         p.n = (int)plan.len;
         p.sgn = inverse ? (T)-1 : (T)1;
         grid = (long long)((batch + k.f - 1) / k.f);
+        if (grid > kMaxGrid) return MI355FFT_ERR_INVALID_ARG;
         k.launch(&p, grid, stream);
     } else if (k.kind == KIND_RADER) {
         RaderParams<T> p{};
@@ -1055,6 +1062,7 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         p.p = (int)plan.len;
         p.sgn = inverse ? (T)-1 : (T)1;
         grid = (long long)((batch + k.f - 1) / k.f);
+        if (grid > kMaxGrid) return MI355FFT_ERR_INVALID_ARG;
         k.launch(&p, grid, stream);
     } else {
         K2Params<T> p{};
@@ -1095,6 +1103,7 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
             p.xq = xq;
         }
         grid = (long long)batch * p.tiles_per_fft;
+        if (grid > kMaxGrid) return MI355FFT_ERR_INVALID_ARG;
         k.launch(&p, grid, stream);
     }
     if (tr) tr->after((int)pi, stream);
