@@ -480,7 +480,10 @@ MI_HD void rader_body(X& ex, const RaderParams<T>& p, long long block, void* lds
     const long long rows_here = (batch - fft0) < F ? (batch - fft0) : F;
     const int valid = (int)(rows_here * P);
     if constexpr (MODE == 1) {
-        constexpr int XS = S::phys(M - 1) + 1;  // first slot past the exchange span: x[0], then X[0]
+        // x[0], then X[0]: a slot past BOTH the exchange span (physical slots < phys(M-1) + 1) and the natural-order outputs
+        // the last scatter writes (logical indices <= M = p - 1).  An unpadded layout has phys(M-1) + 1 == M, which IS the
+        // target of the output with g^-(j+1) = p - 1: the slot must not be below p (round 2: a race that a rescheduling exposed).
+        constexpr int XS = (S::phys(M - 1) + 1 > P) ? S::phys(M - 1) + 1 : P;
         static_assert(XS < PITCH && P <= PITCH, "row pitch must leave a spare slot");
         ex.for_threads([&](int tid, cx<T>*) {
             for (int t = tid; t < F * P; t += NT) {
@@ -587,7 +590,8 @@ template <class S> struct RaderRows {
     static constexpr int M = S::N, P = S::N + 1, NT = S::TPF, EM = S::emax();
     static constexpr int NL = (P + NT - 1) / NT;  // elements of a row each thread loads / stores
     static constexpr int TW0 = EM, D0 = TW0 + twreg_count<S>(), PO0 = D0 + EM, PI0 = PO0 + EM, XN0 = PI0 + NL, NREG = XN0 + NL;
-    static constexpr int XS = S::phys(M - 1) + 1;  // first slot past the exchange span: x[0], then X[0]; XS + 1: dump slot
+    // first slot past the exchange span AND past the natural-order outputs (indices <= M): x[0], then X[0]; XS + 1: dump slot
+    static constexpr int XS = (S::phys(M - 1) + 1 > P) ? S::phys(M - 1) + 1 : P;
 };
 template <class T, class S, int ROWS, bool PREFETCH, class X>
 MI_HD void rader_rows_body(X& ex, const RaderParams<T>& p, long long block, void* lds) {

@@ -2,6 +2,7 @@
 // (MI355_EMU, tests/emu only): HostExec runs every thread of a workgroup phase by phase on the CPU,
 // which checks all index arithmetic of the kernel bodies without a GPU.
 #pragma once
+#include <cstdlib>
 #include <vector>
 
 #include "kernels.h"
@@ -306,12 +307,23 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
 }
 #else
 // -------------------------------------------------------------------------------- host emulator
+// MI355_EMU_ORDER=reverse runs the threads of every phase from the last to the first: a write-write or read-write race
+// between threads of one phase (which the GPU resolves by timing) then shows up as a changed result -- the emulator's
+// cheap race detector (tests/test_kernel_bodies_emu.py::test_thread_order_independence).
+inline bool emu_reverse_order() {
+    const char* e = getenv("MI355_EMU_ORDER");
+    return e && e[0] == 'r';
+}
 template <class T, int NREG> struct HostExec {
     int nt;
+    bool reverse;
     std::vector<cx<T>> regs;
-    explicit HostExec(int n) : nt(n), regs((size_t)n * NREG, cx<T>{0, 0}) {}
+    explicit HostExec(int n) : nt(n), reverse(emu_reverse_order()), regs((size_t)n * NREG, cx<T>{0, 0}) {}
     template <class Fn> void for_threads(Fn&& fn) {
-        for (int t = 0; t < nt; ++t) fn(t, regs.data() + (size_t)t * NREG);
+        if (reverse)
+            for (int t = nt - 1; t >= 0; --t) fn(t, regs.data() + (size_t)t * NREG);
+        else
+            for (int t = 0; t < nt; ++t) fn(t, regs.data() + (size_t)t * NREG);
     }
     void barrier() {}
     void relaunder() {}

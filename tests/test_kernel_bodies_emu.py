@@ -417,3 +417,27 @@ def test_pair_fused_column_tiles(emu_planner, oracle):
                 check_fft_algorithm(fft, n, d, reference=oracle.plan(np.complex64, n, d), n=2)
     finally:
         del os.environ["MI355FFT_VARIANT"]
+
+
+def test_thread_order_independence(emu_planner, oracle):
+    """The emulator runs the threads of a phase one after another, so a race between threads of one phase is invisible to it
+    unless the order changes: MI355_EMU_ORDER=reverse runs every phase from the last thread to the first.  Results must not
+    depend on the order (round 2: the Rader bodies kept X[0] in a slot that the output with g^-(j+1) = p - 1 also wrote
+    whenever the schedule's LDS layout is unpadded -- invisible in thread order, wrong in reverse order, a coin toss on the GPU)."""
+    lengths = [541, 911, 1009, 127, 257, 1201, 2311, 719, 1019, 1200, 4096, 1 << 13, 1 << 16, 44100, 289, 992]
+    os.environ["MI355_EMU_ORDER"] = "reverse"
+    try:
+        for dtype in (np.complex64, np.complex128):
+            planner = emu_planner(dtype)
+            for n in lengths:
+                for d in (0, 1):
+                    fft = planner.plan_fft(n, d)
+                    x = random_signal(2 * n, dtype)
+                    y = x.copy()
+                    fft.process(y)
+                    want = x.copy()
+                    oracle.plan(dtype, n, d).process(want)
+                    assert compare_vectors(want, y), (n, d, fft.describe())
+                    assert rel_l2(y, numpy_fft(x, n, d == 1)) < (5e-6 if dtype == np.complex64 else 1e-13), (n, d, fft.describe())
+    finally:
+        del os.environ["MI355_EMU_ORDER"]
