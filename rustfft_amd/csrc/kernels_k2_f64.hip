@@ -8,6 +8,14 @@ void register_k2_f64(std::vector<KernelEntry>& reg) {
     MI_K2(double, 64, 16, false, 256, 16, 16, 16);
     MI_K2(double, 64, 8, false, 512, 32, 16, 8, 4);
     // (16-column split tile for 512 rows: measured 5 % slower in f64, not instantiated)
-    MI_K2(double, 64, 8, true, 1024, 32, 16, 16, 4);
+    // 1024-row tile: 8 columns (128-byte segments) on 512 threads x 16 values, split exchange, two workgroups per CU.  Round 1 ran it
+    // on 256 threads x 32 values (168 - 180 VGPRs, 8 waves per CU): interleaved A/B at 2^20 f64, first / later pass 3.95 / 4.09 TB/s
+    // against 5.20 / 4.67 (radices 16 16 4) and 5.10 / 4.83 (8 8 16) with 16 values per thread -- each kind takes its better schedule.
+    MI_K2_FIRST(double, 64, 8, true, 1024, 64, 16, 16, 4);
+    MI_K2_LATER(double, 64, 8, true, 1024, 64, 8, 8, 16);
+    MI_K2V(39, double, 64, 8, true, 1024, 32, 16, 16, 4);
+    MI_K2V(42, double, 64, 8, true, 512, 32, 16, 8, 4);
+    // 2048-row tile (2^21, 2^22 in two passes instead of three): 8 columns on 1024 threads x 16 values, one workgroup per CU
+    MI_K2(double, 64, 8, true, 2048, 128, 16, 16, 8);
 }
 }  // namespace mi355

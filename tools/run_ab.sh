@@ -1,8 +1,4 @@
 mkdir -p gpurun_out/r2
-python tools/prime_sweep.py > gpurun_out/r2/primes2.json 2>/dev/null
-python - <<'PY'
-import json
-d=json.load(open('gpurun_out/r2/primes2.json')); print(json.dumps(d['summary']))
-r=[x for x in d['primes'] if x[2]=='rader']; print(sorted(r,key=lambda x:x[1])[:8]); print(sorted(r,key=lambda x:-x[1])[:8])
-PY
-python bench.py --config c4 --no-pmc --no-cpu-baseline 2>/dev/null | cut -c1-900
+python tools/ab.py --oop --dtype f64 --log2n 21 --batch 256 min min:MI355FFT_MAXR=1024 2>&1 | grep arm | cut -c1-330 | tee gpurun_out/r2/ab10.jsonl
+python tools/ab.py --oop --dtype f64 --log2n 22 --batch 128 min min:MI355FFT_MAXR=1024 2>&1 | grep arm | cut -c1-330 | tee -a gpurun_out/r2/ab10.jsonl
+python tools/ab.py --oop --dtype f64 --log2n 20 --batch 512 min min:MI355FFT_VARIANT=39 2>&1 | grep arm | cut -c1-330 | tee -a gpurun_out/r2/ab10.jsonl
