@@ -439,8 +439,16 @@ def main():
                            "kernels": per_kernel,
                            "transform_algorithmic_frac": (batch * 2 * n * 8) / (sum(r["ms"] for r in per_kernel) * 1e-3) / 1e9 / HBM_PEAK_GBS}
         try:
-            cc = copy_ceiling_gbps(torch)
-            out["roofline"]["copy_ceiling"] = {"GBps": cc, "frac_of_copy": dom["GBps"] / cc, "what": "torch device-to-device copy of 2 GiB, read + write bytes"}
+            import ctypes
+
+            from rustfft_amd import _native
+
+            g = ctypes.c_double(0.0)
+            if _native.load().mi355fft_measure_copy_ceiling(2 << 30, ctypes.byref(g)) != 0:
+                raise RuntimeError("mi355fft_measure_copy_ceiling failed")
+            out["roofline"]["copy_ceiling"] = {"GBps": g.value, "frac_of_copy": dom["GBps"] / g.value,
+                                               "what": "fastest plain device copy of 2 GiB on this box (one float4 per thread, read + write bytes; the guide's 6.29 TB/s)",
+                                               "torch_d2d_GBps": copy_ceiling_gbps(torch)}
         except Exception as e:
             log(f"copy ceiling unavailable: {e}")
         if world == 1 and not args.no_pmc:

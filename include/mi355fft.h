@@ -148,6 +148,10 @@ const char* mi355fft_plan_kernel_name(const mi355fft_plan* plan, int index);
  * recorded on that stream; ms_per_kernel[i] receives the mean duration of kernel i in milliseconds. */
 int mi355fft_profile_inplace_dev(const mi355fft_plan* plan, void* buffer, size_t batch, void* stream, int reps,
                                  float* ms_per_kernel, int n_kernels);
+/* Read + write GB/s of the fastest plain device copy of `bytes` bytes (one float4 per thread, huge grid -- the access
+ * pattern that reaches the chip's measured 6.2 - 6.3 TB/s): the data-movement ceiling bench.py quotes next to the 8 TB/s
+ * spec.  Allocates and frees two scratch buffers of that size. */
+int mi355fft_measure_copy_ceiling(size_t bytes, double* gbps);
 /* Tunables (0 = library default): transforms per workspace chunk of the multi-pass path. */
 int mi355fft_plan_set_chunk_batch(mi355fft_plan* plan, size_t chunk_batch);
 /* Plan-owned HBM workspaces (one per stream the plan was used on, kept for reuse): bytes currently held, and a

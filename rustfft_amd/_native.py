@@ -16,7 +16,7 @@ EXPORTS = [
     "mi355fft_process_inplace_host", "mi355fft_process_outofplace_host", "mi355fft_process_immutable_host",
     "mi355fft_process_inplace_dev", "mi355fft_process_outofplace_dev", "mi355fft_process_immutable_dev",
     "mi355fft_plan_num_kernels", "mi355fft_plan_kernel_name", "mi355fft_profile_inplace_dev",
-    "mi355fft_plan_set_chunk_batch", "mi355fft_plan_workspace_bytes", "mi355fft_plan_trim_workspaces", "mi355fft_strerror", "mi355fft_last_error", "mi355fft_version",
+    "mi355fft_measure_copy_ceiling", "mi355fft_plan_set_chunk_batch", "mi355fft_plan_workspace_bytes", "mi355fft_plan_trim_workspaces", "mi355fft_strerror", "mi355fft_last_error", "mi355fft_version",
 ]
 
 
@@ -57,6 +57,7 @@ def bind(lib):
     lib.mi355fft_plan_kernel_name.restype = ctypes.c_char_p
     lib.mi355fft_plan_kernel_name.argtypes = [vp, ci]
     lib.mi355fft_profile_inplace_dev.argtypes = [vp, vp, sz, vp, ci, ctypes.POINTER(ctypes.c_float), ci]
+    lib.mi355fft_measure_copy_ceiling.argtypes = [sz, ctypes.POINTER(ctypes.c_double)]
     lib.mi355fft_plan_set_chunk_batch.argtypes = [vp, sz]
     lib.mi355fft_plan_workspace_bytes.restype = sz
     lib.mi355fft_plan_workspace_bytes.argtypes = [vp]

@@ -23,5 +23,8 @@ void* event_create();
 void event_destroy(void* e);
 void event_record(void* e, void* stream);
 float event_elapsed_ms(void* a, void* b);  // synchronises on b
+// read + write GB/s of the fastest plain copy this chip does (one float4 per thread, huge grid): the measured data-movement
+// ceiling bench.py quotes next to the 8 TB/s spec (MI355X_MICROARCH.md: 6.29 TB/s); 0 on failure
+double copy_ceiling_gbps(size_t bytes);
 }  // namespace backend
 }  // namespace mi355

@@ -64,5 +64,40 @@ float event_elapsed_ms(void* a, void* b) {
     (void)hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b);
     return ms;
 }
+typedef float copy_v4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void copy_f4_kernel(const copy_v4* __restrict__ in, copy_v4* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    out[i] = in[i];
+}
+double copy_ceiling_gbps(size_t bytes) {
+    bytes = (bytes / 4096) * 4096;
+    if (bytes == 0 || bytes / 4096 > 0x7fffffffULL) return 0.0;
+    void *a = nullptr, *b = nullptr;
+    if (hipMalloc(&a, bytes) != hipSuccess) return 0.0;
+    if (hipMalloc(&b, bytes) != hipSuccess) {
+        (void)hipFree(a);
+        return 0.0;
+    }
+    (void)hipMemset(a, 1, bytes);
+    (void)hipMemset(b, 2, bytes);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    const unsigned grid = (unsigned)(bytes / 4096);
+    const int reps = 8;
+    copy_f4_kernel<<<grid, 256>>>((const copy_v4*)a, (copy_v4*)b);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0, nullptr);
+    for (int i = 0; i < reps; ++i) copy_f4_kernel<<<grid, 256>>>((const copy_v4*)a, (copy_v4*)b);
+    (void)hipEventRecord(e1, nullptr);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    return ms > 0 ? 2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9 : 0.0;
+}
 }  // namespace backend
 }  // namespace mi355

@@ -249,6 +249,12 @@ int mi355fft_profile_inplace_dev(const mi355fft_plan* plan, void* buffer, size_t
     for (int i = 0; i < nk; ++i) ms[i] = (float)(tr.total_ms[i] / reps);
     return MI355FFT_OK;
 }
+int mi355fft_measure_copy_ceiling(size_t bytes, double* gbps) {
+    if (!gbps) return set_err(MI355FFT_ERR_INVALID_ARG, "gbps is null");
+    if (int rc = ensure_init()) return rc;
+    *gbps = backend::copy_ceiling_gbps(bytes);
+    return *gbps > 0 ? MI355FFT_OK : set_err(MI355FFT_ERR_HIP, "copy measurement failed");
+}
 int mi355fft_plan_set_chunk_batch(mi355fft_plan* plan, size_t chunk_batch) {
     if (!plan) return set_err(MI355FFT_ERR_INVALID_ARG, "null plan");
     plan->p.chunk_batch = chunk_batch;
