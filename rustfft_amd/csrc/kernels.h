@@ -324,7 +324,10 @@ template <class T, class S2> struct BluesteinRegSrc {
         });
     }
 };
-template <class T, class S, int F, class X>
+// SPLIT (real / imaginary planes exchanged one after the other): with no staged spectrum, a padded length up to 32768 (f64:
+// 16384) fits one workgroup's LDS, so lengths up to 16384 run in ONE kernel at 2 n elements of traffic (round 1: two
+// whole-row kernels through an HBM workspace, 2 M + 2 n elements).
+template <class T, class S, int F, bool SPLIT = false, class X>
 MI_HD void bluestein_body(X& ex, const BluesteinParams<T>& p, long long block, void* lds) {
     using S2 = typename reversed_sched<S>::type;
     static_assert(S2::R[0] == S::R[S::NP - 1] && S2::nb(0) == S::nb(S::NP - 1) && S2::bpt(0) == S::bpt(S::NP - 1), "register hand-over");
@@ -344,7 +347,7 @@ MI_HD void bluestein_body(X& ex, const BluesteinParams<T>& p, long long block, v
         }
         return cx<T>{0, 0};
     };
-    wg_fft<T, S, F, MAP_EF, MAP_EF, false>(ex, lds, p.tw, elem_src(src1), KeepInRegs{});
+    wg_fft<T, S, F, MAP_EF, MAP_EF, SPLIT>(ex, lds, p.tw, elem_src(src1), KeepInRegs{});
     // (the engine's barrier after the last gather of the first transform already orders it before the second one's scatters)
     auto dst2 = [=](int f, int j, cx<T> v) {
         if (f < rows && j < n) {
@@ -353,7 +356,7 @@ MI_HD void bluestein_body(X& ex, const BluesteinParams<T>& p, long long block, v
             out[(unsigned)(f * n + j)] = y;
         }
     };
-    wg_fft<T, S2, F, MAP_EF, MAP_EF, false>(ex, lds, p.tw2, BluesteinRegSrc<T, S2>{p.bf}, dst2);
+    wg_fft<T, S2, F, MAP_EF, MAP_EF, SPLIT>(ex, lds, p.tw2, BluesteinRegSrc<T, S2>{p.bf}, dst2);
 }
 
 // ---- run-time scheduled batched transform (13-smooth lengths) ------------------------------------------------

@@ -18,6 +18,11 @@ void register_k1_f32(std::vector<KernelEntry>& reg) {
     MI_K1V(21, float, 32, 2, false, 1024, 64, 16, 16, 4);
     MI_K1V(21, float, 32, 1, false, 2048, 128, 16, 16, 8);
     // two-kernel Bluestein for 4096 < n <= 16384 (padded lengths 3 * 2^12, 2^14, 3 * 2^13, 2^15)
+    // one-kernel Bluestein for 4096 < n <= 8192: split exchange, spectrum handed over in registers (measured 626 / 1020 GB/s at
+    // n = 4099 / 7919 against 470 / 690 for the two-kernel form; the 1024-thread bodies for M = 24576, 32768 spill under the
+    // 128-VGPR cap and lose to it: 458 against 642 at n = 10007, so 8192 < n <= 16384 keeps two kernels)
+    MI_BSS(float, 32, 1, 12288, 512, 32, 24, 16);
+    MI_BSS(float, 32, 1, 16384, 512, 16, 32, 32);
     MI_BS2(float, 32, 1, true, 12288, 512, 32, 24, 16);
     MI_BS2(float, 32, 1, true, 16384, 512, 16, 32, 32);
     MI_BS2(float, 32, 1, true, 24576, 1024, 32, 32, 24);

@@ -136,11 +136,11 @@ template <class T, class S, int F, bool FIRST, bool SPLIT, int ABL = 0> KernelEn
     };
     return e;
 }
-template <class T, class S, int F>
+template <class T, class S, int F, bool SPLIT = false>
 __global__ __launch_bounds__(F* S::TPF) void bluestein_kernel(BluesteinParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    DevExec<T, regs_needed<S, false>() + twreg_count<S>()> ex;
-    bluestein_body<T, S, F>(ex, p, (long long)blockIdx.x, smem);
+    DevExec<T, regs_needed<S, false>()> ex;
+    bluestein_body<T, S, F, SPLIT>(ex, p, (long long)blockIdx.x, smem);
 }
 template <class T, class S, int F, int MODE>
 // MODE 2: rows loop with next-row prefetch (>= 3 waves per SIMD in f32); MODE 3: without the prefetch; MODE 4: as MODE 2 for the
@@ -173,15 +173,15 @@ template <class T> KernelEntry make_pointwise(int prec) {
     e.prepare = []() -> int { return 0; };
     return e;
 }
-template <class T, class S, int F> constexpr size_t bluestein_lds() {
+template <class T, class S, int F, bool SPLIT = false> constexpr size_t bluestein_lds() {
     using S2 = typename reversed_sched<S>::type;  // the second transform runs the reversed schedule (kernels.h bluestein_body)
-    return (size_t)F * (S::pitch() > S2::pitch() ? S::pitch() : S2::pitch()) * sizeof(cx<T>);
+    return (size_t)F * (S::pitch() > S2::pitch() ? S::pitch() : S2::pitch()) * (SPLIT ? sizeof(T) : sizeof(cx<T>));
 }
 template <class T, class S, int F, int MODE> constexpr size_t rader_lds() {
     return (size_t)(MODE >= 2 ? 1 : F) * (S::pitch() + (MODE >= 1 ? 0 : S::N + 1)) * sizeof(cx<T>);
 }
 
-template <class T, class S, int F> KernelEntry make_bluestein(int prec, const char* name) {
+template <class T, class S, int F, bool SPLIT = false> KernelEntry make_bluestein(int prec, const char* name) {
     KernelEntry e{};
     e.kind = KIND_BLUESTEIN;
     e.prec = prec;
@@ -189,16 +189,16 @@ template <class T, class S, int F> KernelEntry make_bluestein(int prec, const ch
     e.f = F;
     fill_sched<S>(e);
     e.threads = F * S::TPF;
-    e.lds_bytes = bluestein_lds<T, S, F>();
+    e.lds_bytes = bluestein_lds<T, S, F, SPLIT>();
     e.name = name;
     e.launch = [](const void* params, long long grid, void* stream) {
         void* args[] = {const_cast<void*>(params)};
-        (void)hipLaunchKernel((const void*)bluestein_kernel<T, S, F>, dim3((unsigned)grid), dim3(F * S::TPF), args,
-                              bluestein_lds<T, S, F>(), (hipStream_t)stream);
+        (void)hipLaunchKernel((const void*)bluestein_kernel<T, S, F, SPLIT>, dim3((unsigned)grid), dim3(F * S::TPF), args,
+                              bluestein_lds<T, S, F, SPLIT>(), (hipStream_t)stream);
     };
     e.prepare = []() -> int {
-        return (int)hipFuncSetAttribute((const void*)bluestein_kernel<T, S, F>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)bluestein_lds<T, S, F>());
+        return (int)hipFuncSetAttribute((const void*)bluestein_kernel<T, S, F, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)bluestein_lds<T, S, F, SPLIT>());
     };
     return e;
 }
@@ -411,14 +411,14 @@ template <class T> KernelEntry make_pointwise(int prec) {
     e.prepare = []() -> int { return 0; };
     return e;
 }
-template <class T, class S, int F> constexpr size_t bluestein_lds() {
+template <class T, class S, int F, bool SPLIT = false> constexpr size_t bluestein_lds() {
     using S2 = typename reversed_sched<S>::type;  // the second transform runs the reversed schedule (kernels.h bluestein_body)
-    return (size_t)F * (S::pitch() > S2::pitch() ? S::pitch() : S2::pitch()) * sizeof(cx<T>);
+    return (size_t)F * (S::pitch() > S2::pitch() ? S::pitch() : S2::pitch()) * (SPLIT ? sizeof(T) : sizeof(cx<T>));
 }
 template <class T, class S, int F, int MODE> constexpr size_t rader_lds() {
     return (size_t)(MODE >= 2 ? 1 : F) * (S::pitch() + (MODE >= 1 ? 0 : S::N + 1)) * sizeof(cx<T>);
 }
-template <class T, class S, int F> KernelEntry make_bluestein(int prec, const char* name) {
+template <class T, class S, int F, bool SPLIT = false> KernelEntry make_bluestein(int prec, const char* name) {
     KernelEntry e{};
     e.kind = KIND_BLUESTEIN;
     e.prec = prec;
@@ -426,13 +426,13 @@ template <class T, class S, int F> KernelEntry make_bluestein(int prec, const ch
     e.f = F;
     fill_sched<S>(e);
     e.threads = F * S::TPF;
-    e.lds_bytes = bluestein_lds<T, S, F>();
+    e.lds_bytes = bluestein_lds<T, S, F, SPLIT>();
     e.name = name;
     e.launch = [](const void* params, long long grid, void*) {
-        std::vector<char> lds(bluestein_lds<T, S, F>() + 64, (char)0x5a);
+        std::vector<char> lds(bluestein_lds<T, S, F, SPLIT>() + 64, (char)0x5a);
         for (long long b = 0; b < grid; ++b) {
-            HostExec<T, regs_needed<S, false>() + twreg_count<S>()> ex(F * S::TPF);
-            bluestein_body<T, S, F>(ex, *(const BluesteinParams<T>*)params, b, lds.data());
+            HostExec<T, regs_needed<S, false>()> ex(F * S::TPF);
+            bluestein_body<T, S, F, SPLIT>(ex, *(const BluesteinParams<T>*)params, b, lds.data());
         }
     };
     e.prepare = []() -> int { return 0; };
@@ -584,6 +584,8 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
     reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, false, 3>(PREC, "k2glast_chirp<" #__VA_ARGS__ ">xF" #F))
 // Bluestein bodies take the linear exchange layout (SchedL): 164 -> 124 VGPRs for the power-of-two inner lengths
 #define MI_BS(T, PREC, F, ...) reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F))
+// one-kernel Bluestein through the split exchange (padded lengths above 8192: one workgroup per row)
+#define MI_BSS(T, PREC, F, ...) reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F, true>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F "s"))
 #if defined(MI355_TUNING)
 #define MI_BSV(V, T, PREC, F, ...)                                                                    \
     reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F "v" #V)); \

@@ -607,3 +607,30 @@ def test_every_prime_below_1000_and_prime_radices(planners, oracle, dtype):
         if n <= limit:
             assert fft.describe().startswith("k1<%d," % n), (n, fft.describe())
         check_fft_algorithm(fft, n, 0, reference=oracle.plan(dtype, n, 0), n=3)
+
+
+def test_repeatability_bit_for_bit(planners):
+    """A transform is a pure function of its input: five runs of every kernel family on the same HBM-resident input must
+    agree bit for bit.  A write-write or read-write race between threads (round 2: the Rader X[0] slot) shows up here as
+    run-to-run differences long before it shows up as a tolerance failure."""
+    import torch
+
+    lengths = [17, 127, 257, 541, 911, 1009, 1201, 2311, 4051,     # Rader family (all three body forms)
+               719, 1019, 4093, 4099, 7919, 10007, 65537,            # Bluestein: one kernel, split one kernel, fused multi-kernel
+               289, 899, 1200, 4096, 5000, 1 << 14, 25000,           # compiled schedules incl. prime radices, whole-row split kernels
+               4836, 20449, 44100, 1 << 17, 1 << 20, 1 << 22]        # run-time scheduled, general and power-of-two column tiles
+    for dtype, tdtype in ((np.complex64, torch.complex64), (np.complex128, torch.complex128)):
+        planner = planners[np.dtype(dtype)]
+        for n in lengths:
+            batch = max(3, min(4096, (1 << 22) // n))
+            x = torch.from_numpy(random_signal(n * batch, dtype, seed=n)).cuda()
+            fft = planner.plan_fft_forward(n)
+            first = None
+            for _ in range(5):
+                y = x.clone()
+                fft.process(y)
+                torch.cuda.synchronize()
+                if first is None:
+                    first = y
+                else:
+                    assert torch.equal(torch.view_as_real(first), torch.view_as_real(y)), (n, np.dtype(dtype).name, fft.describe())

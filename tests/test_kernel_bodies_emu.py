@@ -186,6 +186,8 @@ def test_lengths_beyond_one_workgroup(emu_planner, oracle, dtype):
             fft = planner.plan_fft(n, d)
             if n == 5000:
                 assert "k1<5000" in fft.describe()
+            elif n <= 8192:  # round 2: ONE kernel -- split exchange, the spectrum handed over in registers (padded length <= 16384)
+                assert fft.describe().startswith("bluestein<") and fft.describe().endswith("s"), fft.describe()
             elif n <= two_kernel_limit:
                 assert fft.describe().startswith("bluestein2_first<") and "bluestein2_second<" in fft.describe(), fft.describe()
             else:
@@ -204,7 +206,7 @@ def test_lengths_beyond_one_workgroup(emu_planner, oracle, dtype):
     os.environ["MI355FFT_BLUESTEIN_UNFUSED"] = "1"
     try:
         fresh = emu_planner(dtype)
-        for n in (4097, 10007):
+        for n in (8209, 10007):  # (lengths up to 8192 are one-kernel plans since round 2)
             fft = fresh.plan_fft(n, 1)
             assert "bluestein_large" in fft.describe() and "fused" not in fft.describe()
             check_fft_algorithm(fft, n, 1, reference=oracle.plan(dtype, n, 1), n=2)
