@@ -23,8 +23,6 @@ void register_k1_f32(std::vector<KernelEntry>& reg) {
     // 128-VGPR cap and lose to it: 458 against 642 at n = 10007, so 8192 < n <= 16384 keeps two kernels)
     MI_BSS(float, 32, 1, 12288, 512, 32, 24, 16);
     MI_BSS(float, 32, 1, 16384, 512, 16, 32, 32);
-    MI_BS2(float, 32, 1, true, 12288, 512, 32, 24, 16);
-    MI_BS2(float, 32, 1, true, 16384, 512, 16, 32, 32);
     MI_BS2(float, 32, 1, true, 24576, 1024, 32, 32, 24);
     MI_BS2(float, 32, 1, true, 32768, 1024, 32, 32, 32);
     MI_K1V(4, float, 32, 1, true, 8192, 512, 16, 8, 8, 8);
