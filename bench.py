@@ -280,6 +280,8 @@ def main():
                          "c4 N=1009 f32 x2^20; c5 N=2^22 f32 x1024 per GPU (8192 over 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the one-GPU control-flow smoke test)")
+    ap.add_argument("--one-device", action="store_true", help="smoke test of the N > 1 control flow on a one-GPU box: every rank uses cuda:0")
     ap.add_argument("--selftest-spawn", action="store_true", help="CPU self-test of the --gpus launcher (gloo): no GPU work")
     ap.add_argument("--edges", action="store_true", help="at --gpus > 1 also time the scatter / gather edges (batch originating on rank 0)")
     ap.add_argument("--no-config5", action="store_true", help="at --gpus > 1: skip the nested BASELINE config-5 measurement")
@@ -300,12 +302,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)  # before the process group: RCCL binds the communicator to the current device
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     def log(msg):
         if rank == 0:
