@@ -1,0 +1,21 @@
+// One-kernel Bluestein bodies over the 5 * 2^k and 7 * 2^k inner lengths, Complex<float>: with the 2^k and 3 * 2^k ones
+// (kernels_np2_f32.hip, kernel_lists.h) the planner's "smallest compiled M >= 2n - 1" pads by less than 1.25x instead of
+// 1.33x (the reference pads to 2^k or 3 * 2^k, src/plan.rs:649-657; every pass of the kernel runs over M, not n).
+#define MI355_PK_CMUL 1
+#include "launch.h"
+namespace mi355 {
+void register_bs57_f32(std::vector<KernelEntry>& reg) {
+    MI_BS(float, 32, 1, 320, 64, 5, 8, 8);
+    MI_BS(float, 32, 1, 448, 64, 7, 8, 8);
+    MI_BS(float, 32, 1, 640, 80, 8, 8, 10);
+    MI_BS(float, 32, 1, 896, 112, 8, 8, 14);
+    MI_BS(float, 32, 1, 1280, 128, 16, 10, 8);
+    MI_BS(float, 32, 1, 1792, 128, 16, 16, 7);
+    MI_BS(float, 32, 1, 2560, 256, 16, 16, 10);
+    MI_BS(float, 32, 1, 3584, 256, 16, 16, 14);
+    MI_BS(float, 32, 1, 5120, 512, 16, 16, 20);
+    MI_BS(float, 32, 1, 7168, 512, 16, 16, 28);
+    MI_BSS(float, 32, 1, 10240, 512, 32, 20, 16);
+    MI_BSS(float, 32, 1, 14336, 512, 32, 28, 16);
+}
+}  // namespace mi355

@@ -37,6 +37,8 @@ void ensure_registry() {
         return;
 #endif
         register_np2_f64(r);
+        register_bs57_f32(r);
+        register_bs57_f64(r);
         register_k2g_f32_0(r);
         register_k2g_f32_1(r);
         register_k2g_f32_2(r);

@@ -40,6 +40,8 @@ void register_k2_f32(std::vector<KernelEntry>&);
 void register_k2_f64(std::vector<KernelEntry>&);
 void register_np2_f32(std::vector<KernelEntry>&);  // non-power-of-two: mixed radix, Rader, Bluestein
 void register_np2_f64(std::vector<KernelEntry>&);
+void register_bs57_f32(std::vector<KernelEntry>&);  // Bluestein bodies over 5 * 2^k and 7 * 2^k
+void register_bs57_f64(std::vector<KernelEntry>&);
 // generated: large-N pass kernels for 7-smooth tile heights (tools/gen_k2g_kernels.py)
 void register_k2g_f32_0(std::vector<KernelEntry>&);
 void register_k2g_f32_1(std::vector<KernelEntry>&);

@@ -174,6 +174,26 @@ def test_baseline_configs_3_and_4(emu_planner, oracle, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_bluestein_inner_length_ladder(emu_planner, oracle, dtype):
+    """The one-kernel Bluestein bodies are compiled for M = 2^k, 3 * 2^k, 5 * 2^k and 7 * 2^k; the planner takes the
+    smallest M >= 2n - 1 (never more than 1.25x of padding from M = 256 on; the reference pads to 2^k or 3 * 2^k,
+    src/plan.rs:649-657).  One length per new M, both directions, against the reference's plan for that length."""
+    import rustfft_amd
+
+    planner = emu_planner(dtype)
+    for n, M in ((150, 320), (200, 448), (300, 640), (401, 896), (601, 1280), (881, 1792), (1201, 2560), (1789, 3584),
+                 (2311, 5120), (3581, 7168), (5003, 10240), (7001, 14336)):
+        assert planner.bluestein_inner_len(n) == M, (n, planner.bluestein_inner_len(n))
+        for d in (0, 1):
+            fft = planner.plan_fft_with(n, d, algorithm=rustfft_amd.ALGO_BLUESTEIN)
+            assert fft.describe().startswith("bluestein<%d," % M), fft.describe()
+            check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=3)
+    # padding stays below 1.25x of the minimum from n = 129 up to the one-kernel limit
+    for n in range(129, 7169):
+        assert planner.bluestein_inner_len(n) * 4 < (2 * n - 1) * 5, n
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_lengths_beyond_one_workgroup(emu_planner, oracle, dtype):
     """Non-powers of two above 4096: a prime the reference plans as Rader (10007), a 'difficult' prime it plans as
     Bluestein (5759), a product of two large primes (101 * 103 -> MixedRadix): two-kernel Bluestein here while the padded
