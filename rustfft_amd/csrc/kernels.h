@@ -595,12 +595,14 @@ template <class S> struct RaderRows {
     static constexpr int TW0 = EM, D0 = TW0 + twreg_count<S>(), PO0 = D0 + EM, PI0 = PO0 + EM, XN0 = PI0 + NL, NREG = XN0 + NL;
     // first slot past the exchange span AND past the natural-order outputs (indices <= M): x[0], then X[0]; XS + 1: dump slot
     static constexpr int XS = (S::phys(M - 1) + 1 > P) ? S::phys(M - 1) + 1 : P;
+    // LDS slots of the one row buffer: the exchange span, the natural-order outputs and the two spare slots
+    static constexpr int SLOTS = (S::pitch() > XS + 2) ? S::pitch() : XS + 2;
 };
 template <class T, class S, int ROWS, bool PREFETCH, class X>
 MI_HD void rader_rows_body(X& ex, const RaderParams<T>& p, long long block, void* lds) {
     using L = RaderRows<S>;
-    constexpr int P = L::P, PITCH = S::pitch(), NT = L::NT, NL = L::NL, XS = L::XS;
-    static_assert(XS + 1 < PITCH && P <= PITCH, "row pitch must leave two spare slots");
+    constexpr int P = L::P, NT = L::NT, NL = L::NL, XS = L::XS;
+    static_assert(XS + 1 < L::SLOTS && P <= L::SLOTS, "the row buffer holds two spare slots");
     const cx<T>* in = p.in;
     cx<T>* out = p.out;
     const T sgn = p.sgn;

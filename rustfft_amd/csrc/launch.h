@@ -178,7 +178,8 @@ template <class T, class S, int F, bool SPLIT = false> constexpr size_t bluestei
     return (size_t)F * (S::pitch() > S2::pitch() ? S::pitch() : S2::pitch()) * (SPLIT ? sizeof(T) : sizeof(cx<T>));
 }
 template <class T, class S, int F, int MODE> constexpr size_t rader_lds() {
-    return (size_t)(MODE >= 2 ? 1 : F) * (S::pitch() + (MODE >= 1 ? 0 : S::N + 1)) * sizeof(cx<T>);
+    if (MODE >= 2) return (size_t)RaderRows<S>::SLOTS * sizeof(cx<T>);  // one row at a time
+    return (size_t)F * (S::pitch() + (MODE >= 1 ? 0 : S::N + 1)) * sizeof(cx<T>);
 }
 
 template <class T, class S, int F, bool SPLIT = false> KernelEntry make_bluestein(int prec, const char* name) {
@@ -416,7 +417,8 @@ template <class T, class S, int F, bool SPLIT = false> constexpr size_t bluestei
     return (size_t)F * (S::pitch() > S2::pitch() ? S::pitch() : S2::pitch()) * (SPLIT ? sizeof(T) : sizeof(cx<T>));
 }
 template <class T, class S, int F, int MODE> constexpr size_t rader_lds() {
-    return (size_t)(MODE >= 2 ? 1 : F) * (S::pitch() + (MODE >= 1 ? 0 : S::N + 1)) * sizeof(cx<T>);
+    if (MODE >= 2) return (size_t)RaderRows<S>::SLOTS * sizeof(cx<T>);  // one row at a time
+    return (size_t)F * (S::pitch() + (MODE >= 1 ? 0 : S::N + 1)) * sizeof(cx<T>);
 }
 template <class T, class S, int F, bool SPLIT = false> KernelEntry make_bluestein(int prec, const char* name) {
     KernelEntry e{};

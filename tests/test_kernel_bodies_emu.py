@@ -292,6 +292,23 @@ def test_runtime_scheduled_kernels(emu_planner, oracle, dtype):
             check_fft_algorithm(fft, p, d, reference=oracle.plan(dtype, p, d), n=3)
 
 
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_compiled_rader_bodies_every_form(emu_planner, oracle, dtype):
+    """tools/gen_rader_kernels.py picks one of five body forms per prime (staged rows, rows side by side, and the rows loop
+    with / without prefetch at two register budgets): primes of every form, including the ones whose row pitch leaves no
+    spare slot past the exchange span (1297, 2003, 2081: the rows loop sizes its own buffer) and the five f64 rows-loop
+    bodies, both directions, ragged batch, against the reference's plan."""
+    planner = emu_planner(dtype)
+    f32 = dtype == np.complex64
+    want = ({257: "m0", 541: "m1", 811: "m2", 1201: "m2", 1297: "m4", 2003: "m4", 2081: "m4", 4051: "m2", 4057: "m4"} if f32 else
+            {257: "m0", 541: "m1", 727: "m3", 811: "m3", 991: "m3", 1459: "m3", 2801: "m3", 1297: "m1", 2081: "m0"})
+    for p, form in want.items():
+        for d in (0, 1):
+            fft = planner.plan_fft(p, d)
+            assert fft.describe().startswith("rader<%d," % (p - 1)) and fft.describe().endswith(form), (p, fft.describe())
+            check_fft_algorithm(fft, p, d, reference=oracle.plan(dtype, p, d), n=11)  # 11 rows: one full group of 8 and a ragged one
+
+
 def _thirteen_smooth(limit):
     s = {1}
     for p in (2, 3, 5, 7, 11, 13):
@@ -446,7 +463,7 @@ def test_thread_order_independence(emu_planner, oracle):
     unless the order changes: MI355_EMU_ORDER=reverse runs every phase from the last thread to the first.  Results must not
     depend on the order (round 2: the Rader bodies kept X[0] in a slot that the output with g^-(j+1) = p - 1 also wrote
     whenever the schedule's LDS layout is unpadded -- invisible in thread order, wrong in reverse order, a coin toss on the GPU)."""
-    lengths = [541, 911, 1009, 127, 257, 1201, 2311, 719, 1019, 1200, 4096, 1 << 13, 1 << 16, 44100, 289, 992]
+    lengths = [541, 911, 1009, 127, 257, 1201, 2311, 1297, 2003, 2081, 727, 2801, 719, 1019, 1200, 1281, 2311 + 2, 4096, 1 << 13, 1 << 16, 44100, 289, 992]
     os.environ["MI355_EMU_ORDER"] = "reverse"
     try:
         for dtype in (np.complex64, np.complex128):

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Every prime p <= 4096 through the planner's AUTO choice, forward, HBM-resident, 1 GiB of rows each: algorithmic TB/s
 (2 * p * sizeof(C) per transform / time) and the fraction of 8 TB/s, grouped by plan family.  Prints ONE JSON object:
-{"primes": [[p, TBps, family], ...], "summary": {family: {"count", "min", "median", "max"}}}."""
+{"primes": [[p, TBps, family], ...], "summary": {family: {"count", "min", "median", "max"}}}.  --dtype f64 for Complex<f64>."""
 import json
 import os
 import statistics
@@ -16,7 +16,8 @@ def main():
 
     import rustfft_amd
 
-    dt, tdt, esz = np.complex64, torch.complex64, 8
+    f64 = "--dtype" in sys.argv and sys.argv[sys.argv.index("--dtype") + 1] == "f64"
+    dt, tdt, esz = (np.complex128, torch.complex128, 16) if f64 else (np.complex64, torch.complex64, 8)
     planner = rustfft_amd.FftPlanner(dt)
     primes = [p for p in range(2, 4097) if all(p % q for q in range(2, int(p**0.5) + 1))]
     rows = []
@@ -46,7 +47,7 @@ def main():
         v = [r[1] for r in rows if r[2] == fam]
         summary[fam] = {"count": len(v), "min_TBps": min(v), "median_TBps": statistics.median(v), "max_TBps": max(v),
                         "min_frac_of_8TBps": round(min(v) / 8, 3), "median_frac_of_8TBps": round(statistics.median(v) / 8, 3)}
-    print(json.dumps({"what": "every prime <= 4096, Complex<f32>, forward, 1 GiB of rows, AUTO plan", "summary": summary, "primes": rows}))
+    print(json.dumps({"what": "every prime <= 4096, Complex<%s>, forward, 1 GiB of rows, AUTO plan" % ("f64" if f64 else "f32"), "summary": summary, "primes": rows}))
 
 
 if __name__ == "__main__":

@@ -28,6 +28,8 @@ python tools/sweep.py --dtype f64 --sizes $NP2 --check > $OUT/sweep_np2_f64.json
 # 5. every prime <= 4096 (the planner's Rader / prime-radix / Bluestein split): AUTO against forced Bluestein, a sample
 python tools/algo_compare.py --dtype f32 --sizes 17,31,73,127,257,401,541,761,1009,1019,1201,1453,2003,2311,3001,4001,4051,4093 > $OUT/primes_auto_vs_bluestein_f32.jsonl 2>/dev/null
 python tools/prime_sweep.py > $OUT/primes_le_4096_f32.json 2>/dev/null
+python tools/prime_sweep.py --dtype f64 > $OUT/primes_le_4096_f64.json 2>/dev/null
+python tools/bs_ladder.py > $OUT/bluestein_ladder.jsonl 2>/dev/null
 # 6. issue / stall breakdown (SQ counters, two passes each)
 ( cd /tmp && python $ROOT/tools/pmc_sq.py --steps 2 --warmup 1 > $OUT/sq_counters_c2.jsonl 2>/dev/null )
 ( cd /tmp && python $ROOT/tools/pmc_sq.py --config c4 --steps 2 --warmup 1 > $OUT/sq_counters_c4.jsonl 2>/dev/null )
