@@ -294,14 +294,17 @@ def test_runtime_scheduled_kernels(emu_planner, oracle, dtype):
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_compiled_rader_bodies_every_form(emu_planner, oracle, dtype):
-    """tools/gen_rader_kernels.py picks one of five body forms per prime (staged rows, rows side by side, and the rows loop
-    with / without prefetch at two register budgets): primes of every form, including the ones whose row pitch leaves no
-    spare slot past the exchange span (1297, 2003, 2081: the rows loop sizes its own buffer) and the five f64 rows-loop
-    bodies, both directions, ragged batch, against the reference's plan."""
+    """tools/gen_rader_kernels.py picks a body form per prime (rows side by side, or the rows loop with / without prefetch at
+    two register budgets; by measurement where the forms compete): primes of every form, including the ones whose row pitch
+    leaves no spare slot past the exchange span (1297, 2003, 2081: the rows loop sizes its own buffer), the primes below 800
+    that take a wider schedule to reach 64 threads per row, and f64 rows-loop bodies; both directions, ragged batch, against
+    the reference's plan."""
     planner = emu_planner(dtype)
     f32 = dtype == np.complex64
-    want = ({257: "m0", 541: "m1", 811: "m2", 1201: "m2", 1297: "m4", 2003: "m4", 2081: "m4", 4051: "m2", 4057: "m4"} if f32 else
-            {257: "m0", 541: "m1", 727: "m3", 811: "m3", 991: "m3", 1459: "m3", 2801: "m3", 1297: "m1", 2081: "m0"})
+    want = ({97: "m1", 127: "m1", 193: "m2", 257: "m2", 449: "m2", 541: "m2", 769: "m2", 811: "m2", 1201: "m2", 1297: "m4", 2003: "m4",
+             2081: "m4", 4051: "m2", 4057: "m4"} if f32 else
+            {97: "m1", 127: "m1", 193: "m3", 257: "m3", 541: "m3", 727: "m3", 811: "m3", 911: "m1", 1201: "m3", 1297: "m3", 2081: "m3",
+             2801: "m3", 3697: "m3", 4057: "m1"})
     for p, form in want.items():
         for d in (0, 1):
             fft = planner.plan_fft(p, d)

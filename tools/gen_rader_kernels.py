@@ -20,7 +20,15 @@ import gen_smooth_kernels as g
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NFILES = 4
-F64_ROWS = {727, 811, 991, 1459, 2801}
+# Measured choices (profiles/r2/rader_ab1_*.json: every prime through the default choice and through "rows loop wherever it
+# can be instantiated", same box, 1 GiB of rows; a prime is listed when the alternative ran > 5 % faster):
+# f64 rows-loop bodies with the default schedule (the first five compile without scratch, the others spill 8 .. 100 bytes per
+# lane and still win)
+F64_ROWS = {727, 811, 991, 1459, 2801, 1201, 1297, 1373, 1621, 1783, 1801, 1951, 2081, 2251, 2593, 2663, 3169, 3457, 3697, 4051}
+# primes below ~800 whose default schedule has fewer than 64 threads per row: schedule_wide + the rows loop (1.1 - 2.3x)
+WIDE_ROWS = ({(32, p) for p in (193, 257, 271, 281, 331, 337, 353, 397, 401, 421, 433, 449, 463, 487, 491, 541, 577, 601, 617, 631, 641,
+                                661, 673, 769)} |
+             {(64, p) for p in (193, 211, 241, 257, 281, 331, 337, 397, 401, 421, 433, 449, 463, 487, 491, 541, 577, 601, 641, 769)})
 SKIP = {1009}  # hand-tuned instantiation in kernels_np2_*.hip
 
 
@@ -50,9 +58,38 @@ def layout(n, rad, tpf):
     return pitch, xs, emax, twreg
 
 
+def schedule_wide(n, e=12):
+    """A three-sub-pass schedule with radices <= e and at least 64 threads per row (one butterfly per thread in the widest
+    sub-pass): what lets a prime below ~700 run the rows loop.  None if n has no such factorisation."""
+    best = None
+    for rad in g.factorizations(n):
+        if max(rad) > e or len(rad) > 3:
+            continue
+        t = max(n // r for r in rad)
+        if t < 64:
+            continue
+        util = sum((n // r) / t for r in rad) / len(rad) * t / (math.ceil(t / 64) * 64)
+        if best is None or util > best[0]:
+            best = (util, sorted(rad, reverse=True), t)
+    return (best[1], best[2]) if best else None
+
+
+ALT = os.environ.get("RADER_ALT") == "1"  # experiment 1: the rows loop wherever it can be instantiated (A/B against the default choice)
+ALT2 = os.environ.get("RADER_ALT") == "2"  # experiment 2: one butterfly per thread, smallest radices, for the primes with >= 64 threads per row
+
+
 def choose(p, prec):
     n = p - 1
     rad, tpf = g.schedule(n)
+    wide = (prec, p) in WIDE_ROWS
+    if (ALT or wide) and tpf < 64 and schedule_wide(n):
+        rad, tpf = schedule_wide(n)
+    if ALT2 and tpf >= 64:
+        for e in (12, 13, 14, 15, 16):
+            w = schedule_wide(n, e)
+            if w and w[1] <= 512:
+                rad, tpf = w
+                break
     pitch, xs, emax, twreg = layout(n, rad, tpf)
     esz = 8 if prec == 32 else 16
     nl = math.ceil(p / tpf)
@@ -63,7 +100,7 @@ def choose(p, prec):
     # f64 (MODE 3, no prefetch): 256 VGPRs at two waves per SIMD hold the per-thread tables of few schedules -- the ones listed
     # compile without scratch (hipcc -Rpass-analysis=kernel-resource-usage over all 68 candidates with >= 64 threads per row;
     # the others spill 8 .. 220 bytes per lane, mostly in the radix-11 / 13 / 15 butterflies, and stay MODE 1)
-    if prec == 64 and p in F64_ROWS:
+    if prec == 64 and (p in F64_ROWS or wide or (ALT and tpf >= 64) or (ALT2 and tpf >= 64 and (rad, tpf) != g.schedule(n))):
         return (8, 3, rad, tpf)
     if prec == 32 and tpf >= 64 and nreg <= 118:  # tables up to 256 VGPRs, two waves per SIMD
         return (8, 4, rad, tpf)

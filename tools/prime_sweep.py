@@ -18,7 +18,12 @@ def main():
 
     f64 = "--dtype" in sys.argv and sys.argv[sys.argv.index("--dtype") + 1] == "f64"
     dt, tdt, esz = (np.complex128, torch.complex128, 16) if f64 else (np.complex64, torch.complex64, 8)
-    planner = rustfft_amd.FftPlanner(dt)
+    if "--lib" in sys.argv:  # an alternative build of the library (A/B of generator choices)
+        from rustfft_amd import _native
+
+        planner = rustfft_amd.FftPlannerHip(dt, lib=_native.load(sys.argv[sys.argv.index("--lib") + 1]))
+    else:
+        planner = rustfft_amd.FftPlanner(dt)
     primes = [p for p in range(2, 4097) if all(p % q for q in range(2, int(p**0.5) + 1))]
     rows = []
     x = torch.empty((1 << 30) // esz, dtype=tdt, device="cuda")
