@@ -74,6 +74,10 @@ def schedule_wide(n, e=12):
     return (best[1], best[2]) if best else None
 
 
+# primes with >= 64 threads per row that run faster with one butterfly per thread and the smallest radices (profiles/r2/rader_ab2_*.json,
+# same method: 1.1 - 2.2x)
+WIDE2_ROWS = ({(32, p) for p in (701, 727, 757, 881, 883, 1297)} |
+              {(64, p) for p in (881, 883, 937, 1051, 1153, 1171, 1249, 1321, 1373, 1409, 1471, 1801)})
 ALT = os.environ.get("RADER_ALT") == "1"  # experiment 1: the rows loop wherever it can be instantiated (A/B against the default choice)
 ALT2 = os.environ.get("RADER_ALT") == "2"  # experiment 2: one butterfly per thread, smallest radices, for the primes with >= 64 threads per row
 
@@ -84,7 +88,8 @@ def choose(p, prec):
     wide = (prec, p) in WIDE_ROWS
     if (ALT or wide) and tpf < 64 and schedule_wide(n):
         rad, tpf = schedule_wide(n)
-    if ALT2 and tpf >= 64:
+    wide2 = (prec, p) in WIDE2_ROWS
+    if (ALT2 or wide2) and tpf >= 64:
         for e in (12, 13, 14, 15, 16):
             w = schedule_wide(n, e)
             if w and w[1] <= 512:
@@ -100,7 +105,7 @@ def choose(p, prec):
     # f64 (MODE 3, no prefetch): 256 VGPRs at two waves per SIMD hold the per-thread tables of few schedules -- the ones listed
     # compile without scratch (hipcc -Rpass-analysis=kernel-resource-usage over all 68 candidates with >= 64 threads per row;
     # the others spill 8 .. 220 bytes per lane, mostly in the radix-11 / 13 / 15 butterflies, and stay MODE 1)
-    if prec == 64 and (p in F64_ROWS or wide or (ALT and tpf >= 64) or (ALT2 and tpf >= 64 and (rad, tpf) != g.schedule(n))):
+    if prec == 64 and (p in F64_ROWS or wide or wide2 or (ALT and tpf >= 64) or (ALT2 and tpf >= 64 and (rad, tpf) != g.schedule(n))):
         return (8, 3, rad, tpf)
     if prec == 32 and tpf >= 64 and nreg <= 118:  # tables up to 256 VGPRs, two waves per SIMD
         return (8, 4, rad, tpf)
