@@ -78,12 +78,29 @@ def schedule_wide(n, e=12):
 # same method: 1.1 - 2.2x)
 WIDE2_ROWS = ({(32, p) for p in (701, 727, 757, 881, 883, 1297)} |
               {(64, p) for p in (881, 883, 937, 1051, 1153, 1171, 1249, 1321, 1373, 1409, 1471, 1801)})
+# primes whose p - 1 has a prime factor 17 .. 31 (schedule31: prime-radix sub-passes): 99 of them <= 4096; as Rader bodies most
+# lose to the one-kernel Bluestein (median 0.9x), these win by 7 - 59 % (profiles/r2/rader_ab3_*.json) -- mostly where
+# Bluestein has to pad 2p - 1 up to 5120 or 6144
+EXTRA31 = ({(32, p) for p in (137, 523, 571, 613, 647, 683, 2089, 2129, 2143, 2281, 2347, 2381, 2531, 2857)} |
+           {(64, p) for p in (571, 613, 647, 1123, 2053, 2129, 2143, 2281, 2393, 2437, 2531, 2843, 3469, 3571, 3673, 3877, 3911)})
+ALT4 = os.environ.get("RADER_ALT") == "4"  # experiment 4: MODE 4 for the f32 MODE 2 bodies that spill; rows loop for EXTRA31
+MODE2_SPILLS = {991, 1301, 1453, 2179, 2917, 2971, 4051}
 ALT = os.environ.get("RADER_ALT") == "1"  # experiment 1: the rows loop wherever it can be instantiated (A/B against the default choice)
 ALT2 = os.environ.get("RADER_ALT") == "2"  # experiment 2: one butterfly per thread, smallest radices, for the primes with >= 64 threads per row
 
 
 def choose(p, prec):
     n = p - 1
+    if (prec, p) in EXTRA31:
+        rad, tpf = g.schedule31(n)
+        pitch, xs, emax, twreg = layout(n, rad, tpf)
+        esz = 8 if prec == 32 else 16
+        if ALT4 and tpf >= 64:
+            return (8, 4 if prec == 32 else 3, rad, tpf)
+        f = max(1, min(256 // tpf, (60 * 1024) // (pitch * esz)))
+        if xs < pitch and p <= pitch:
+            return (f, 1, rad, tpf)
+        return (max(1, min(256 // tpf, (60 * 1024) // ((pitch + p) * esz))), 0, rad, tpf)
     rad, tpf = g.schedule(n)
     wide = (prec, p) in WIDE_ROWS
     if (ALT or wide) and tpf < 64 and schedule_wide(n):
@@ -101,7 +118,7 @@ def choose(p, prec):
     nreg = 3 * emax + twreg + 2 * nl
     # (the rows loop sizes its one row buffer itself -- kernels.h RaderRows::SLOTS -- so the pitch rounding does not matter here)
     if prec == 32 and tpf >= 64 and nreg <= 80:
-        return (8, 2, rad, tpf)
+        return (8, 4 if (ALT4 and p in MODE2_SPILLS) else 2, rad, tpf)
     # f64 (MODE 3, no prefetch): 256 VGPRs at two waves per SIMD hold the per-thread tables of few schedules -- the ones listed
     # compile without scratch (hipcc -Rpass-analysis=kernel-resource-usage over all 68 candidates with >= 64 threads per row;
     # the others spill 8 .. 220 bytes per lane, mostly in the radix-11 / 13 / 15 butterflies, and stay MODE 1)
@@ -118,9 +135,10 @@ def choose(p, prec):
 
 def main():
     s13 = set(g.smooth(4096, [2, 3, 5, 7, 11, 13]))
-    primes = [p for p in range(17, 4097) if is_prime(p) and (p - 1) in s13 and p not in SKIP]
+    primes13 = [p for p in range(17, 4097) if is_prime(p) and (p - 1) in s13 and p not in SKIP]
     for tag, ty, prec in (("f32", "float", 32), ("f64", "double", 64)):
         modes = {}
+        primes = sorted(primes13 + [p for (pr, p) in EXTRA31 if pr == prec])
         for ci in range(NFILES):
             lines = []
             for p in primes[ci::NFILES]:
@@ -130,7 +148,7 @@ def main():
             path = os.path.join(ROOT, "rustfft_amd", "csrc", f"kernels_rader_{tag}_{ci}.hip")
             with open(path, "w") as fh:
                 fh.write(f"// GENERATED by tools/gen_rader_kernels.py — do not edit.  Compiled Rader bodies for the primes <= 4096 whose p - 1 is\n"
-                         f"// 13-smooth (part {ci + 1} of {NFILES}), Complex<{ty}>.\n"
+                         f"// 13-smooth, and the few with a factor 17 .. 31 that beat Bluestein (part {ci + 1} of {NFILES}), Complex<{ty}>.\n"
                          + ("#define MI355_PK_CMUL 1\n" if prec == 32 else "") +
                          '#include "launch.h"\nnamespace mi355 {\n'
                          f"void register_rader_{tag}_{ci}(std::vector<KernelEntry>& reg) {{\n" + "\n".join(lines) + "\n}\n}  // namespace mi355\n")
