@@ -83,8 +83,9 @@ WIDE2_ROWS = ({(32, p) for p in (701, 727, 757, 881, 883, 1297)} |
 # Bluestein has to pad 2p - 1 up to 5120 or 6144
 EXTRA31 = ({(32, p) for p in (137, 523, 571, 613, 647, 683, 2089, 2129, 2143, 2281, 2347, 2381, 2531, 2857)} |
            {(64, p) for p in (571, 613, 647, 1123, 2053, 2129, 2143, 2281, 2393, 2437, 2531, 2843, 3469, 3571, 3673, 3877, 3911)})
-ALT4 = os.environ.get("RADER_ALT") == "4"  # experiment 4: MODE 4 for the f32 MODE 2 bodies that spill; rows loop for EXTRA31
-MODE2_SPILLS = {991, 1301, 1453, 2179, 2917, 2971, 4051}
+# f32 bodies whose tables spill at MODE 2's 168 VGPRs and run 5 - 23 % faster at MODE 4's 256 (profiles/r2/rader_ab4_*.json; 1301
+# is the one spiller that loses 24 % and stays; the same run: the rows loop for the EXTRA31 primes loses 5 - 60 %)
+MODE4_F32 = {991, 1453, 2179, 2917, 2971, 4051}
 ALT = os.environ.get("RADER_ALT") == "1"  # experiment 1: the rows loop wherever it can be instantiated (A/B against the default choice)
 ALT2 = os.environ.get("RADER_ALT") == "2"  # experiment 2: one butterfly per thread, smallest radices, for the primes with >= 64 threads per row
 
@@ -95,8 +96,6 @@ def choose(p, prec):
         rad, tpf = g.schedule31(n)
         pitch, xs, emax, twreg = layout(n, rad, tpf)
         esz = 8 if prec == 32 else 16
-        if ALT4 and tpf >= 64:
-            return (8, 4 if prec == 32 else 3, rad, tpf)
         f = max(1, min(256 // tpf, (60 * 1024) // (pitch * esz)))
         if xs < pitch and p <= pitch:
             return (f, 1, rad, tpf)
@@ -118,7 +117,7 @@ def choose(p, prec):
     nreg = 3 * emax + twreg + 2 * nl
     # (the rows loop sizes its one row buffer itself -- kernels.h RaderRows::SLOTS -- so the pitch rounding does not matter here)
     if prec == 32 and tpf >= 64 and nreg <= 80:
-        return (8, 4 if (ALT4 and p in MODE2_SPILLS) else 2, rad, tpf)
+        return (8, 4 if p in MODE4_F32 else 2, rad, tpf)
     # f64 (MODE 3, no prefetch): 256 VGPRs at two waves per SIMD hold the per-thread tables of few schedules -- the ones listed
     # compile without scratch (hipcc -Rpass-analysis=kernel-resource-usage over all 68 candidates with >= 64 threads per row;
     # the others spill 8 .. 220 bytes per lane, mostly in the radix-11 / 13 / 15 butterflies, and stay MODE 1)
