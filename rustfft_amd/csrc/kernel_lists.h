@@ -30,10 +30,12 @@
     MI_BS(T, PREC, 8, 64, 8, 8, 8);                \
     MI_BS(T, PREC, 8, 128, 8, 16, 8);              \
     MI_BS(T, PREC, 2, 256, 32, 8, 8, 4);           \
-    MI_BS(T, PREC, 1, 4096, 256, 16, 16, 16)
+    MI_BS(T, PREC, 1, 4096, 512, 8, 8, 8, 8)
 
 // Bluestein bodies over the 3 * 2^k inner lengths (the reference's second family, src/plan.rs:649-657): the planner takes
 // the smallest compiled M >= 2n - 1, so the worst-case padding drops from 2x to 1.33x
+// (sub-pass order: measured per inner length with tools/bs_ladder.py, profiles/r2/bluestein_schedules_ab.txt -- the smallest
+// radix first and the radix-16 sub-passes next to the register hand-over run 3 - 25 % faster than largest-first)
 #define MI_BS_LIST3_F32(T, PREC)                  \
     MI_BS(T, PREC, 256, 12, 1, 12);  \
     MI_BS(T, PREC, 128, 24, 2, 12, 2);  \
@@ -41,9 +43,9 @@
     MI_BS(T, PREC, 8, 96, 8, 16, 6);  \
     MI_BS(T, PREC, 16, 192, 16, 16, 12);  \
     MI_BS(T, PREC, 1, 384, 64, 6, 8, 8);  \
-    MI_BS(T, PREC, 1, 768, 96, 8, 8, 12);  \
-    MI_BS(T, PREC, 1, 1536, 128, 16, 16, 6);  \
-    MI_BS(T, PREC, 1, 3072, 256, 16, 16, 12);  \
+    MI_BS(T, PREC, 1, 768, 64, 12, 8, 8);  \
+    MI_BS(T, PREC, 1, 1536, 256, 6, 16, 16);  \
+    MI_BS(T, PREC, 1, 3072, 256, 12, 16, 16);  \
     MI_BS(T, PREC, 1, 6144, 512, 16, 16, 24)
 #define MI_BS_LIST3_F64(T, PREC)                  \
     MI_BS(T, PREC, 256, 12, 1, 12);  \
@@ -52,7 +54,7 @@
     MI_BS(T, PREC, 8, 96, 8, 16, 6);  \
     MI_BS(T, PREC, 16, 192, 16, 16, 12);  \
     MI_BS(T, PREC, 1, 384, 64, 6, 8, 8);  \
-    MI_BS(T, PREC, 1, 768, 96, 8, 8, 12);  \
-    MI_BS(T, PREC, 2, 1536, 128, 16, 16, 6);  \
-    MI_BS(T, PREC, 1, 3072, 256, 16, 16, 12);  \
+    MI_BS(T, PREC, 1, 768, 64, 12, 8, 8);  \
+    MI_BS(T, PREC, 1, 1536, 256, 6, 16, 16);  \
+    MI_BS(T, PREC, 1, 3072, 256, 12, 16, 16);  \
     MI_BS(T, PREC, 1, 6144, 512, 16, 16, 24)

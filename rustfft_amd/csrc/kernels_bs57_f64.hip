@@ -4,15 +4,19 @@ namespace mi355 {
 void register_bs57_f64(std::vector<KernelEntry>& reg) {
     MI_BS(double, 64, 1, 320, 64, 5, 8, 8);
     MI_BS(double, 64, 1, 448, 64, 7, 8, 8);
-    MI_BS(double, 64, 1, 640, 80, 8, 8, 10);
+    MI_BS(double, 64, 1, 640, 80, 10, 8, 8);
     MI_BS(double, 64, 1, 896, 112, 8, 8, 14);
-    MI_BS(double, 64, 1, 1280, 128, 16, 10, 8);
+    MI_BS(double, 64, 1, 1280, 128, 5, 16, 16);
     MI_BS(double, 64, 1, 1792, 128, 16, 16, 7);
-    MI_BS(double, 64, 1, 2560, 256, 16, 16, 10);
-    MI_BS(double, 64, 1, 3584, 256, 16, 16, 14);
+    MI_BS(double, 64, 1, 2560, 256, 10, 16, 16);
+    MI_BS(double, 64, 1, 3584, 256, 14, 16, 16);
     MI_BS(double, 64, 1, 5120, 512, 16, 16, 20);
     MI_BS(double, 64, 1, 7168, 512, 16, 16, 28);
     MI_BSS(double, 64, 1, 10240, 640, 16, 16, 10, 4);
     MI_BSS(double, 64, 1, 14336, 512, 16, 16, 14, 4);  // 896 threads cap a thread at 128 VGPRs and spill
+    MI_BSV(1, double, 64, 1, 640, 80, 8, 8, 10);  // tuning: the largest-first order
+    MI_BSV(1, double, 64, 1, 1280, 128, 16, 10, 8);  // tuning: the largest-first order
+    MI_BSV(1, double, 64, 1, 2560, 256, 16, 16, 10);  // tuning: the largest-first order
+    MI_BSV(1, double, 64, 1, 3584, 256, 16, 16, 14);  // tuning: the largest-first order
 }
 }  // namespace mi355

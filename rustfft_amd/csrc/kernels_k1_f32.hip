@@ -23,6 +23,9 @@ void register_k1_f32(std::vector<KernelEntry>& reg) {
     // 128-VGPR cap and lose to it: 458 against 642 at n = 10007, so 8192 < n <= 16384 keeps two kernels)
     MI_BSS(float, 32, 1, 12288, 512, 32, 24, 16);
     MI_BSS(float, 32, 1, 16384, 512, 16, 32, 32);
+    MI_BSV(2, float, 32, 1, 12288, 512, 16, 24, 32);  // tuning: without the split exchange
+    MI_BSV(2, float, 32, 1, 16384, 512, 16, 32, 32);
+    MI_BSSV(3, float, 32, 1, 12288, 512, 16, 24, 32);
     MI_BS2(float, 32, 1, true, 24576, 1024, 32, 32, 24);
     MI_BS2(float, 32, 1, true, 32768, 1024, 32, 32, 32);
     MI_K1V(4, float, 32, 1, true, 8192, 512, 16, 8, 8, 8);

@@ -28,11 +28,21 @@ void register_np2_f32(std::vector<KernelEntry>& reg) {
     MI_RADERV(35, float, 32, 16, 2, 1008, 144, 16, 9, 7);
     MI_RADERV(36, float, 32, 4, 2, 1008, 144, 16, 9, 7);
     MI_BS_LIST(float, 32);
-    MI_BS(float, 32, 2, 512, 64, 8, 8, 8);
-    MI_BS(float, 32, 1, 1024, 64, 16, 16, 4);    // one wave per row: 1.68 TB/s against 1.55 with four rows per workgroup
-    MI_BS(float, 32, 1, 2048, 128, 16, 16, 8);
+    MI_BS(float, 32, 4, 512, 64, 8, 8, 8);
+    MI_BS(float, 32, 1, 1024, 128, 8, 8, 16);  // 3.98 ns per row against 4.25 for 16 x 16 x 4 on one wave
+    MI_BS(float, 32, 1, 2048, 128, 8, 16, 16);  // 8.84 against 9.57 for 16 x 16 x 8
     MI_BS(float, 32, 1, 8192, 512, 16, 16, 32);  // 1.22 TB/s against 0.97 for 16 x 8 x 8 x 8 (one exchange fewer)
     MI_BS_LIST3_F32(float, 32);
+    // tuning: the orders / thread counts the defaults were measured against, and the large inner lengths without the split exchange
+    MI_BSV(1, float, 32, 2, 512, 64, 8, 8, 8);
+    MI_BSV(1, float, 32, 1, 1024, 64, 16, 16, 4);
+    MI_BSV(1, float, 32, 1, 2048, 128, 16, 16, 8);
+    MI_BSV(1, float, 32, 1, 1536, 128, 16, 16, 6);
+    MI_BSV(1, float, 32, 1, 3072, 256, 16, 16, 12);
+    MI_BSV(1, float, 32, 1, 4096, 256, 16, 16, 16);
+    MI_BSV(1, float, 32, 1, 768, 96, 8, 8, 12);
+    MI_BSV(3, float, 32, 1, 6144, 512, 24, 16, 16);
+    MI_BSV(3, float, 32, 1, 8192, 512, 32, 16, 16);
     reg.push_back(make_pointwise<float>(32));
     reg.push_back(make_dyn_k1<float>(32));
     reg.push_back(make_dyn_rader<float>(32));

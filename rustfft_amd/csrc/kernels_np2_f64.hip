@@ -12,11 +12,18 @@ void register_np2_f64(std::vector<KernelEntry>& reg) {
     MI_RADERV(2, double, 64, 1, 1, 1008, 144, 16, 9, 7);
     MI_RADERV(3, double, 64, 8, 2, 1008, 144, 16, 9, 7);
     MI_BS_LIST(double, 64);
-    MI_BS(double, 64, 1, 512, 64, 8, 8, 8);
-    MI_BS(double, 64, 4, 1024, 64, 16, 16, 4);
+    MI_BS(double, 64, 2, 512, 64, 8, 8, 8);
+    MI_BS(double, 64, 2, 1024, 128, 8, 8, 16);  // 6.55 ns per row against 8.04 for 16 x 16 x 4
     MI_BS(double, 64, 2, 2048, 128, 16, 16, 8);
     MI_BS(double, 64, 1, 8192, 512, 16, 8, 8, 8);  // the radix-32 last pass spills in f64
     MI_BS_LIST3_F64(double, 64);
+    // tuning: the orders the defaults were measured against (see kernels_np2_f32.hip)
+    MI_BSV(1, double, 64, 1, 512, 64, 8, 8, 8);
+    MI_BSV(1, double, 64, 4, 1024, 64, 16, 16, 4);
+    MI_BSV(1, double, 64, 2, 1536, 128, 16, 16, 6);
+    MI_BSV(1, double, 64, 1, 3072, 256, 16, 16, 12);
+    MI_BSV(1, double, 64, 1, 4096, 256, 16, 16, 16);
+    MI_BSV(1, double, 64, 1, 768, 96, 8, 8, 12);
     reg.push_back(make_pointwise<double>(64));
     reg.push_back(make_dyn_k1<double>(64));
     reg.push_back(make_dyn_rader<double>(64));

@@ -592,8 +592,12 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
 #define MI_BSV(V, T, PREC, F, ...)                                                                    \
     reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F "v" #V)); \
     reg.back().variant = V
+#define MI_BSSV(V, T, PREC, F, ...)                                                                          \
+    reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F, true>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F "sv" #V)); \
+    reg.back().variant = V
 #else
 #define MI_BSV(V, T, PREC, F, ...) (void)0
+#define MI_BSSV(V, T, PREC, F, ...) (void)0
 #endif
 #define MI_RADER(T, PREC, F, MODE, ...) reg.push_back(make_rader<T, Sched<__VA_ARGS__>, F, MODE>(PREC, "rader<" #__VA_ARGS__ ">xF" #F "m" #MODE))
 #if defined(MI355_TUNING)

@@ -33,12 +33,17 @@ void ensure_registry() {
         register_k2_f32(r);
         register_k2_f64(r);
         register_np2_f32(r);
-#if defined(MI355_MINIMAL)  // `make tuning-min`: power-of-two kernels + the f32 Rader / Bluestein unit (kernel experiments that need a one-minute build)
+#if defined(MI355_MINIMAL)
+        register_bs57_f32(r);
+        register_np2_f64(r);
+        register_bs57_f64(r);  // `make tuning-min`: power-of-two kernels + the f32 Rader / Bluestein unit (kernel experiments that need a one-minute build)
         return;
 #endif
+#if !defined(MI355_MINIMAL)
         register_np2_f64(r);
         register_bs57_f32(r);
         register_bs57_f64(r);
+#endif
         register_k2g_f32_0(r);
         register_k2g_f32_1(r);
         register_k2g_f32_2(r);

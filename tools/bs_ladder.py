@@ -16,7 +16,12 @@ def main():
     import rustfft_amd
 
     for dt, tdt, esz, name in ((np.complex64, torch.complex64, 8, "f32"), (np.complex128, torch.complex128, 16, "f64")):
-        planner = rustfft_amd.FftPlanner(dt)
+        if "--lib" in sys.argv:  # a tuning build (MI355FFT_VARIANT selects alternative bodies there)
+            from rustfft_amd import _native
+
+            planner = rustfft_amd.FftPlannerHip(dt, lib=_native.load(sys.argv[sys.argv.index("--lib") + 1]))
+        else:
+            planner = rustfft_amd.FftPlanner(dt)
         x = torch.empty((1 << 30) // esz, dtype=tdt, device="cuda")
         torch.view_as_real(x).uniform_(-1.0, 1.0)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
