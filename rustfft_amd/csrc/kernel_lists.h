@@ -46,7 +46,7 @@
     MI_BS(T, PREC, 1, 768, 64, 12, 8, 8);  \
     MI_BS(T, PREC, 1, 1536, 256, 6, 16, 16);  \
     MI_BS(T, PREC, 1, 3072, 256, 12, 16, 16);  \
-    MI_BS(T, PREC, 1, 6144, 512, 16, 16, 24)
+    MI_BS(T, PREC, 1, 6144, 512, 6, 8, 8, 16)
 #define MI_BS_LIST3_F64(T, PREC)                  \
     MI_BS(T, PREC, 256, 12, 1, 12);  \
     MI_BS(T, PREC, 128, 24, 2, 12, 2);  \

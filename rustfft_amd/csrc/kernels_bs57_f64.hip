@@ -10,13 +10,15 @@ void register_bs57_f64(std::vector<KernelEntry>& reg) {
     MI_BS(double, 64, 1, 1792, 128, 16, 16, 7);
     MI_BS(double, 64, 1, 2560, 256, 10, 16, 16);
     MI_BS(double, 64, 1, 3584, 256, 14, 16, 16);
-    MI_BS(double, 64, 1, 5120, 512, 16, 16, 20);
+    MI_BS(double, 64, 1, 5120, 640, 8, 8, 8, 10);  // 50.5 ns per row against 58.9 for 16 x 16 x 20
     MI_BS(double, 64, 1, 7168, 512, 16, 16, 28);
-    MI_BSS(double, 64, 1, 10240, 640, 16, 16, 10, 4);
+    MI_BSS(double, 64, 1, 10240, 640, 10, 8, 8, 16);  // 120.0 against 131.8 for 16 x 16 x 10 x 4
     MI_BSS(double, 64, 1, 14336, 512, 16, 16, 14, 4);  // 896 threads cap a thread at 128 VGPRs and spill
     MI_BSV(1, double, 64, 1, 640, 80, 8, 8, 10);  // tuning: the largest-first order
     MI_BSV(1, double, 64, 1, 1280, 128, 16, 10, 8);  // tuning: the largest-first order
     MI_BSV(1, double, 64, 1, 2560, 256, 16, 16, 10);  // tuning: the largest-first order
     MI_BSV(1, double, 64, 1, 3584, 256, 16, 16, 14);  // tuning: the largest-first order
+    MI_BSV(1, double, 64, 1, 5120, 512, 16, 16, 20);  // tuning: the schedules these replaced
+    MI_BSSV(1, double, 64, 1, 10240, 640, 16, 16, 10, 4);
 }
 }  // namespace mi355

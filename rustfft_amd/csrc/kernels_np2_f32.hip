@@ -41,7 +41,7 @@ void register_np2_f32(std::vector<KernelEntry>& reg) {
     MI_BSV(1, float, 32, 1, 3072, 256, 16, 16, 12);
     MI_BSV(1, float, 32, 1, 4096, 256, 16, 16, 16);
     MI_BSV(1, float, 32, 1, 768, 96, 8, 8, 12);
-    MI_BSV(3, float, 32, 1, 6144, 512, 24, 16, 16);
+    MI_BSV(1, float, 32, 1, 6144, 512, 16, 16, 24);
     MI_BSV(3, float, 32, 1, 8192, 512, 32, 16, 16);
     reg.push_back(make_pointwise<float>(32));
     reg.push_back(make_dyn_k1<float>(32));
