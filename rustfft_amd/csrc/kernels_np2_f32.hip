@@ -8,7 +8,17 @@
 #include "kernel_lists.h"
 namespace mi355 {
 void register_np2_f32(std::vector<KernelEntry>& reg) {
-    MI_K1(float, 32, 2, false, 1200, 120, 10, 10, 12);
+    MI_K1(float, 32, 4, false, 1200, 120, 10, 10, 12);  // four rows per workgroup: 4.90 TB/s against 4.64 with two (f64 is fastest with two)
+    // tuning: other orders / tilings of 1200 (tools/ab.py --n 1200 min:MI355FFT_VARIANT=k)
+    MI_K1V(1, float, 32, 2, false, 1200, 120, 12, 10, 10);
+    MI_K1V(2, float, 32, 2, false, 1200, 120, 10, 12, 10);
+    MI_K1V(3, float, 32, 4, false, 1200, 120, 10, 10, 12);
+    MI_K1V(4, float, 32, 1, false, 1200, 120, 10, 10, 12);
+    MI_K1V(5, float, 32, 2, false, 1200, 150, 8, 10, 15);
+    MI_K1V(6, float, 32, 1, false, 1200, 240, 5, 15, 16);
+    MI_K1V(7, float, 32, 3, false, 1200, 80, 15, 16, 5);
+    MI_K1V(8, float, 32, 2, false, 1200, 150, 8, 15, 10);
+    MI_K1V(9, float, 32, 2, false, 1200, 100, 12, 10, 10);
     // Rader 1009: eight rows per workgroup, one after another, every per-thread table in registers (kernels.h
     // rader_rows_body).  Measured on MI355X (2 GiB of rows): 3.0 TB/s, against 2.3 (one row per workgroup, staged rows,
     // variant 1), 2.1 (variant 2: scatter on load, 128 threads) and 2.4 (variant 4: no prefetch of the next row).

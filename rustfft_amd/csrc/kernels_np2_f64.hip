@@ -5,6 +5,16 @@
 namespace mi355 {
 void register_np2_f64(std::vector<KernelEntry>& reg) {
     MI_K1(double, 64, 2, false, 1200, 120, 10, 10, 12);
+    // tuning: other orders / tilings of 1200 (tools/ab.py --n 1200 --dtype f64 min:MI355FFT_VARIANT=k)
+    MI_K1V(1, double, 64, 2, false, 1200, 120, 12, 10, 10);
+    MI_K1V(2, double, 64, 2, false, 1200, 120, 10, 12, 10);
+    MI_K1V(3, double, 64, 4, false, 1200, 120, 10, 10, 12);
+    MI_K1V(4, double, 64, 1, false, 1200, 120, 10, 10, 12);
+    MI_K1V(5, double, 64, 2, false, 1200, 150, 8, 10, 15);
+    MI_K1V(6, double, 64, 1, false, 1200, 240, 5, 15, 16);
+    MI_K1V(7, double, 64, 3, false, 1200, 80, 15, 16, 5);
+    MI_K1V(8, double, 64, 2, false, 1200, 150, 8, 15, 10);
+    MI_K1V(9, double, 64, 2, false, 1200, 100, 12, 10, 10);
     // f64: the rows loop without the next-row prefetch (it would not fit 256 VGPRs): 2.6 TB/s against 2.06 (variant 1:
     // four staged rows per workgroup) and 2.25 (variant 2: scatter on load, one row)
     MI_RADER(double, 64, 8, 3, 1008, 144, 16, 9, 7);

@@ -92,10 +92,20 @@ void ensure_registry() {
         register_smooth3_f32_5(r);
         register_smooth3_f32_6(r);
         register_smooth3_f32_7(r);
+        register_smooth3_f32_8(r);
+        register_smooth3_f32_9(r);
+        register_smooth3_f32_10(r);
+        register_smooth3_f32_11(r);
+        register_smooth3_f32_12(r);
+        register_smooth3_f32_13(r);
         register_smooth3_f64_0(r);
         register_smooth3_f64_1(r);
         register_smooth3_f64_2(r);
         register_smooth3_f64_3(r);
+        register_smooth3_f64_4(r);
+        register_smooth3_f64_5(r);
+        register_smooth3_f64_6(r);
+        register_smooth3_f64_7(r);
         register_rader_f32_0(r);
         register_rader_f32_1(r);
         register_rader_f32_2(r);

@@ -96,10 +96,20 @@ void register_smooth3_f32_4(std::vector<KernelEntry>&);
 void register_smooth3_f32_5(std::vector<KernelEntry>&);
 void register_smooth3_f32_6(std::vector<KernelEntry>&);
 void register_smooth3_f32_7(std::vector<KernelEntry>&);
+void register_smooth3_f32_8(std::vector<KernelEntry>&);
+void register_smooth3_f32_9(std::vector<KernelEntry>&);
+void register_smooth3_f32_10(std::vector<KernelEntry>&);
+void register_smooth3_f32_11(std::vector<KernelEntry>&);
+void register_smooth3_f32_12(std::vector<KernelEntry>&);
+void register_smooth3_f32_13(std::vector<KernelEntry>&);
 void register_smooth3_f64_0(std::vector<KernelEntry>&);
 void register_smooth3_f64_1(std::vector<KernelEntry>&);
 void register_smooth3_f64_2(std::vector<KernelEntry>&);
 void register_smooth3_f64_3(std::vector<KernelEntry>&);
+void register_smooth3_f64_4(std::vector<KernelEntry>&);
+void register_smooth3_f64_5(std::vector<KernelEntry>&);
+void register_smooth3_f64_6(std::vector<KernelEntry>&);
+void register_smooth3_f64_7(std::vector<KernelEntry>&);
 // generated: compiled Rader bodies for the primes <= 4096 with 13-smooth p - 1 (tools/gen_rader_kernels.py)
 void register_rader_f32_0(std::vector<KernelEntry>&);
 void register_rader_f32_1(std::vector<KernelEntry>&);

@@ -505,6 +505,12 @@ def test_runtime_scheduled_kernels(planners, oracle, dtype):
             fft = planner.plan_fft(n, d)
             assert "dyn_k1" in fft.describe(), (n, fft.describe())
             check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=3)
+    if dtype == np.complex64:  # compiled prime-radix schedules reach 4096 in f32 (2048 in f64)
+        for n in [2057, 2108, 3553, 3910, 4048, 4092]:
+            for d in (0, 1):
+                fft = planner.plan_fft(n, d)
+                assert fft.describe().startswith("k1<%d," % n), (n, fft.describe())
+                check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=3)
     for n in [1088, 3553]:  # ... which a host planner can also ask for below 4096 (AUTO prefers compiled schedules / Bluestein there)
         fft = planner.plan_fft_with(n, 0, algorithm=rustfft_amd.ALGO_MIXED_RADIX)
         assert "dyn_k1" in fft.describe() or fft.describe().startswith("k1<"), (n, fft.describe())

@@ -422,8 +422,8 @@ def test_host_planner_options(emu_planner, oracle):
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_prime_radices_17_to_31(emu_planner, oracle, dtype):
     """The reference's Butterfly17 .. Butterfly31 (src/algorithm/butterflies.rs:1582-6241) as in-register prime radices:
-    lengths with such a factor run as mixed-radix kernels -- compiled schedules up to 1024, the run-time scheduled HEAVY
-    kernel above -- and no longer through Bluestein."""
+    lengths with such a factor run as mixed-radix kernels -- compiled schedules up to 4096 (f64: 2048), the run-time
+    scheduled HEAVY kernel above 4096 -- and no longer through Bluestein."""
     planner = emu_planner(dtype)
     for n in (17, 19, 23, 29, 31, 34, 51, 93, 289, 323, 437, 899, 961, 992, 1023):
         for d in (0, 1):
@@ -432,11 +432,11 @@ def test_prime_radices_17_to_31(emu_planner, oracle, dtype):
             check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=3)
     import rustfft_amd
 
-    for n in (1088, 1734, 2465, 3553, 4352, 6448):
+    for n in (1088, 1734, 2465, 3553, 4092, 4352, 6448):
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
-            if n <= 2048 and dtype == np.complex64:
-                assert fft.describe().startswith("k1<%d," % n), (n, fft.describe())  # compiled up to 2048 in f32
+            if n <= (4096 if dtype == np.complex64 else 2048):
+                assert fft.describe().startswith("k1<%d," % n), (n, fft.describe())  # compiled up to 4096 in f32, 2048 in f64
             elif n <= 4096:  # the one-kernel Bluestein measured faster than the run-time scheduled HEAVY kernel ...
                 assert "bluestein" in fft.describe(), (n, fft.describe())
                 fft = planner.plan_fft_with(n, d, algorithm=rustfft_amd.ALGO_MIXED_RADIX)  # ... which a host planner can still ask for
