@@ -806,11 +806,12 @@ template <class T> static int build_plan_t(Plan& plan) {
     if (direct_ok && env_int("MI355FFT_NO_DYN") == 0) {
         DynSched ds;
         const KernelEntry* dk = find_kind(KIND_DYN_K1, plan.prec);
-        // measured (profiles/r2/pr_vs_bs_*.jsonl): the HEAVY set (prime radices 17 .. 31, 32 values per thread) runs at
-        // 0.5 - 1.0 TB/s -- behind the one-kernel Bluestein (1.1 - 1.3, n <= 4096), ahead of the two-kernel one (0.5 - 0.6)
+        // measured (profiles/r2/pr_vs_bs_*.jsonl, heavy_vs_bluestein_above_4096.txt): the HEAVY set (prime radices 17 .. 31, 32
+        // values per thread) runs at 0.5 - 1.0 TB/s -- behind the one-kernel Bluestein wherever that one exists (n <= 8192:
+        // 1.1 - 1.3 TB/s up to 4096, 0.8 - 1.3 through the split exchange above), ahead of the multi-kernel forms.
         // Only the HEAVY set is planned this way: every 13-smooth length has a compiled schedule (<= 4096) or runs in
         // two to four column-tile passes (above), both faster than this kernel (1.0 - 1.8 TB/s).
-        const bool heavy_loses = algo == MI355FFT_ALGO_AUTO && n <= 4096;
+        const bool heavy_loses = algo == MI355FFT_ALGO_AUTO && n <= 8192;
         if (dk && build_dyn_sched(n, 2 * sizeof(T), 0, ds) && ds.light == 2 && !heavy_loses) {
             if (dk->prepare()) return MI355FFT_ERR_HIP;
             plan.kind = PLAN_SINGLE;
