@@ -9,6 +9,7 @@ Schedule choice per length: radices <= 16 (any composite the in-register butterf
 sub-passes first, then the best lane utilisation under the 16-values-per-thread register budget.
 """
 import itertools
+import json
 import math
 import os
 
@@ -61,10 +62,20 @@ def schedule(n, emax=EMAX, max_passes=5):
     return rad, tpf
 
 
+ROWS_TARGET = int(os.environ.get("SMOOTH_ROWS_TARGET", "256"))  # experiment knob: threads per workgroup the row count aims at
+
+
+# rows per workgroup that measured > 4 % faster than the 256-thread rule on MI355X (profiles/r2/smooth_rows_ab_*.json: every
+# length with the 128-, 256- and 512-thread rule, same box, 1 GiB of rows; no single rule wins, so the winners are listed)
+ROWS_CHOICE = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "smooth_rows_choice.json")))
+
+
 def rows_per_wg(n, tpf, esz):
-    f = max(1, round(256 / tpf))
+    if ROWS_TARGET == 256 and str(n) in ROWS_CHOICE["f32" if esz == 8 else "f64"]:
+        return ROWS_CHOICE["f32" if esz == 8 else "f64"][str(n)]
+    f = max(1, round(ROWS_TARGET / tpf))
     pitch = n + n // 8 + 2
-    while f > 1 and (f * pitch * esz > 60 * 1024 or f * tpf > 512):
+    while f > 1 and (f * pitch * esz > 60 * 1024 or f * tpf > max(512, ROWS_TARGET)):
         f -= 1
     return f
 

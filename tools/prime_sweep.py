@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Every prime p <= 4096 through the planner's AUTO choice, forward, HBM-resident, 1 GiB of rows each: algorithmic TB/s
 (2 * p * sizeof(C) per transform / time) and the fraction of 8 TB/s, grouped by plan family.  Prints ONE JSON object:
-{"primes": [[p, TBps, family], ...], "summary": {family: {"count", "min", "median", "max"}}}.  --dtype f64 for Complex<f64>."""
+{"primes": [[p, TBps, family], ...], "summary": {family: {"count", "min", "median", "max"}}}.  --dtype f64 for Complex<f64>;
+--set smooth13 sweeps the 13-smooth non-power-of-two lengths <= 4096 instead (family = rows per workgroup); --lib <path> loads another build."""
 import json
 import os
 import statistics
@@ -25,6 +26,14 @@ def main():
     else:
         planner = rustfft_amd.FftPlanner(dt)
     primes = [p for p in range(2, 4097) if all(p % q for q in range(2, int(p**0.5) + 1))]
+    if "--set" in sys.argv and sys.argv[sys.argv.index("--set") + 1] == "smooth13":  # every 13-smooth non-power-of-two length instead
+        def smooth(v):
+            for q in (2, 3, 5, 7, 11, 13):
+                while v % q == 0:
+                    v //= q
+            return v == 1
+
+        primes = [v for v in range(3, 4097) if smooth(v) and (v & (v - 1))]
     rows = []
     x = torch.empty((1 << 30) // esz, dtype=tdt, device="cuda")
     torch.view_as_real(x).uniform_(-1.0, 1.0)
@@ -45,7 +54,7 @@ def main():
             ts.append(e0.elapsed_time(e1) / 3)
             buf.mul_(1e-3)  # keep magnitudes bounded (unnormalised transforms grow by sqrt(p) per call)
         d = fft.describe()
-        fam = "rader" if d.startswith("rader") or "dyn_rader" in d else "bluestein" if "bluestein" in d else "butterfly/mixed-radix"
+        fam = d.split(">")[1] if d.startswith("k1<") else "rader" if d.startswith("rader") or "dyn_rader" in d else "bluestein" if "bluestein" in d else "butterfly/mixed-radix"
         rows.append([p, round(batch * 2 * p * esz / min(ts) / 1e9, 3), fam])
     summary = {}
     for fam in sorted(set(r[2] for r in rows)):
