@@ -62,16 +62,42 @@ def schedule(n, emax=EMAX, max_passes=5):
     return rad, tpf
 
 
+def schedule_small_radix(n):
+    """Experiment / measured alternative: as many sub-passes as schedule(n), the smallest largest-radix, one butterfly per
+    thread in the widest sub-pass (what the Rader family's A/B favoured for the VALU-heavy radices 11 .. 16)."""
+    rad0, tpf0 = schedule(n)
+    best = None
+    for rad in factorizations(n):
+        if len(rad) != len(rad0):
+            continue
+        tpf = max(n // r for r in rad)
+        if tpf > 512:
+            continue
+        util = sum((n // r) / tpf for r in rad) / len(rad) * (tpf / (math.ceil(tpf / 64) * 64) if tpf >= 64 else 1.0)
+        key = (max(rad), -util)
+        if best is None or key < best[0]:
+            best = (key, sorted(rad, reverse=True), tpf)
+    return (best[1], best[2]) if best else (rad0, tpf0)
+
+
+SCHED_ALT = os.environ.get("SMOOTH_SCHED_ALT") == "1"
 ROWS_TARGET = int(os.environ.get("SMOOTH_ROWS_TARGET", "256"))  # experiment knob: threads per workgroup the row count aims at
 
 
 # rows per workgroup that measured > 4 % faster than the 256-thread rule on MI355X (profiles/r2/smooth_rows_ab_*.json: every
 # length with the 128-, 256- and 512-thread rule, same box, 1 GiB of rows; no single rule wins, so the winners are listed)
-ROWS_CHOICE = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "smooth_rows_choice.json")))
+_CHOICES = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "smooth_rows_choice.json")))
+ROWS_CHOICE = _CHOICES["rows"]
+
+
+# lengths that take schedule_small_radix: 19 f32 / 27 f64 of the 295 / 263 lengths where it differs ran > 4 % faster with it
+# (profiles/r2/smooth_sched_ab_*.json; the median over all of them is 0.91x / 0.99x -- the default rule stays the rule)
+SCHED_CHOICE = {k: {str(n) for n in v} for k, v in _CHOICES["small_radix"].items()}
 
 
 def rows_per_wg(n, tpf, esz):
-    if ROWS_TARGET == 256 and str(n) in ROWS_CHOICE["f32" if esz == 8 else "f64"]:
+    tag = "f32" if esz == 8 else "f64"
+    if ROWS_TARGET == 256 and not SCHED_ALT and str(n) in ROWS_CHOICE[tag] and str(n) not in SCHED_CHOICE[tag]:
         return ROWS_CHOICE["f32" if esz == 8 else "f64"][str(n)]
     f = max(1, round(ROWS_TARGET / tpf))
     pitch = n + n // 8 + 2
@@ -205,6 +231,8 @@ def main():
             lines = []
             for n in chunk:
                 rad, tpf = schedule(n)
+                if SCHED_ALT or str(n) in SCHED_CHOICE[tag]:
+                    rad, tpf = schedule_small_radix(n)
                 f = rows_per_wg(n, tpf, esz)
                 lines.append(f"    MI_K1({ty}, {prec}, {f}, false, {n}, {tpf}, {', '.join(map(str, rad))});")
             path = os.path.join(ROOT, "rustfft_amd", "csrc", f"kernels_smooth_{tag}_{ci}.hip")
