@@ -266,8 +266,28 @@ template <class T, class S, int F, bool FIRST, int FUSE, bool SPLIT = false, cla
 MI_HD void k2g_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     static_assert(FUSE == 0 || (FUSE == 1) == FIRST, "chirp-in fuses into a first pass, the output stages into a last pass");
     constexpr int R = S::N;
-    const long long g = block / p.tiles_per_fft;
-    const unsigned b0 = (unsigned)(block % p.tiles_per_fft) * (unsigned)F;
+    // XCD-aware tile order as in k2_body, over the GLOBAL workgroup index (tile counts are not multiples of 64 here): every
+    // complete aligned group of 64 workgroups is permuted so that XCD x takes runs of 2^XP adjacent tiles (XCD id at address
+    // bits 9 .. 11 of the row segment); the last, partial group keeps the identity order (xfull = number of complete groups).
+    // A group may straddle two transforms: the map is a bijection on workgroup indices either way.  Tiles with row segments of
+    // 512 bytes or more (XP = 0: the identity) and the fused Bluestein passes keep the plain order and the plain index code.
+    constexpr int SEGB = F * (int)sizeof(cx<T>), XP = SEGB >= 512 ? 0 : SEGB >= 256 ? 1 : SEGB >= 128 ? 2 : 3;
+    long long g;
+    unsigned b0;
+    if constexpr (XP > 0 && FUSE == 0) {
+        if (p.xq > 0 && (block >> 6) < (long long)p.xfull) {
+            const int r = (int)(block & 63), x = r & 7, i = r >> 3;
+            const int t = ((i >> XP) << (XP + 3)) | (x << XP) | (i & ((1 << XP) - 1));
+            block += t - r;
+        }
+        // grid <= 2^31 - 1 (plan.cpp kMaxGrid): 32-bit division
+        const unsigned tpf = (unsigned)p.tiles_per_fft;
+        g = (long long)((unsigned)block / tpf);
+        b0 = ((unsigned)block - (unsigned)g * tpf) * (unsigned)F;
+    } else {
+        g = block / p.tiles_per_fft;
+        b0 = (unsigned)(block % p.tiles_per_fft) * (unsigned)F;
+    }
     const cx<T>* in = p.in + g * (FUSE == 1 ? p.n_io : p.n);
     cx<T>* out = p.out + g * (FUSE == 3 ? p.n_io : p.n);
     const unsigned M = (unsigned)p.m, Sg = (unsigned)p.s;

@@ -30,6 +30,7 @@ template <class T> struct K2Params {
     int tiles_shift, s_shift;  // log2(tiles_per_fft), log2(s): the power-of-two passes (k2_body) index with shifts
     int xp, xq;  // XCD-aware tile order (k2_body): groups of 8 << xq workgroups, XCD id placed at tile-index bits [xp, xp+3); xq = 0: identity
     int dbg;   // measurement knobs (bit 0: skip the inter-pass twiddles); 0 in production
+    int xfull;  // k2g_body: number of complete 64-workgroup groups of the grid (the permuted ones)
     // fused multi-kernel Bluestein (k2g_body FUSE != 0): the element-wise stages of bluesteins_algorithm.rs:100-136 ride
     // on the first load / last store of the two inner transforms
     const cx<T>* tab;   // FUSE 1, 3: chirp[n_valid]; FUSE 2: spectrum multiplier bf[N]

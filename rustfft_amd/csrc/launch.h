@@ -226,9 +226,18 @@ template <class T, class S, int F, int MODE> KernelEntry make_rader(int prec, co
     };
     return e;
 }
-// SPLIT (tall tiles): two workgroups per CU, as for the power-of-two tiles
+// Waves per SIMD the compiler must keep (caps the VGPR count).  Split tiles: as for the power-of-two ones.  f64 non-split tiles:
+// four (<= 128 VGPRs; measured +3.4 % in the median over 100 general plans, profiles/r2/k2g_xcd_ab.txt) except the two fused-
+// Bluestein last passes of the 256-row tile (150 / 166 VGPRs).  f32: no request (the compiler then schedules the light kernels
+// for 5 - 8 waves; a request of four costs those 16 - 19 %) except three radix-15-first later passes that sit at 130 - 132 VGPRs
+// without it and lose a fifth of their rate to the occupancy step (measured on k2glater<75>: 4.5 -> 3.4 TB/s at 130 VGPRs).
+template <class T, class S, bool FIRST, int FUSE, bool SPLIT, int THREADS> constexpr int k2g_min_waves() {
+    if (SPLIT) return THREADS >= 512 ? 4 : 2;
+    if (sizeof(T) == 8) return (FUSE >= 2 && S::N >= 256) ? 1 : 4;
+    return (!FIRST && FUSE == 0 && S::R[0] == 15 && (S::N == 300 || S::N == 375 || S::N == 450)) ? 4 : 1;
+}
 template <class T, class S, int F, bool FIRST, int FUSE, bool SPLIT>
-__global__ __launch_bounds__(F* S::TPF, (SPLIT ? (F * S::TPF >= 512 ? 4 : 2) : 1)) void k2g_kernel(K2Params<T> p) {
+__global__ __launch_bounds__(F* S::TPF, (k2g_min_waves<T, S, FIRST, FUSE, SPLIT, F * S::TPF>())) void k2g_kernel(K2Params<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevExec<T, regs_needed<S, SPLIT>()> ex;
     k2g_body<T, S, F, FIRST, FUSE, SPLIT>(ex, p, (long long)blockIdx.x, smem);

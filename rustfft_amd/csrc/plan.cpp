@@ -1122,6 +1122,10 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         }
         grid = (long long)batch * p.tiles_per_fft;
         if (grid > kMaxGrid) return MI355FFT_ERR_INVALID_ARG;
+        if ((k.kind == KIND_K2G_FIRST || k.kind == KIND_K2G_LATER) && !(plan.dbg & 2)) {
+            p.xq = 3;  // k2g_body: XCD-aware order over the global workgroup index (the placement itself is a compile-time constant there)
+            p.xfull = (int)(grid >> 6);
+        }
         k.launch(&p, grid, stream);
     }
     if (tr) tr->after((int)pi, stream);

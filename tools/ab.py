@@ -42,7 +42,8 @@ def main():
     arms = []
     for spec in args.arms:
         name, _, envs = spec.partition(":")
-        path = os.path.join(ROOT, "rustfft_amd", "lib", {"default": "libmi355fft.so", "tuning": "libmi355fft_tuning.so", "min": "libmi355fft_tuning_min.so"}[name])
+        names = {"default": "libmi355fft.so", "tuning": "libmi355fft_tuning.so", "min": "libmi355fft_tuning_min.so"}
+        path = os.path.join(ROOT, "rustfft_amd", "lib", names.get(name, name))  # any other name: a library file in rustfft_amd/lib (an alternative build)
         if path not in libs:
             libs[path] = _native.load(path)
         kv = dict(e.split("=") for e in envs.split(",") if e)
