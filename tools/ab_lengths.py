@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Interleaved A/B of two builds of the library over a set of lengths, in ONE process: for every length both builds plan it,
+both are warmed, then timed alternately (A B A B ...), and the minimum per build is kept.  Separate processes on one box drift
+by several per cent (the first process after the box is acquired is the slowest), so generator choices are confirmed with this
+tool.  Prints one JSON line per length: {"n", "a_TBps", "b_TBps", "b_over_a", "plan_a", "plan_b"}.
+
+  python tools/ab_lengths.py --a libmi355fft.so --b libmi355fft_alt.so --set smooth13 [--dtype f64] [--sizes 1200,1500]"""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import numpy as np
+    import torch
+
+    import rustfft_amd
+    from rustfft_amd import _native
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--a", default="libmi355fft.so")
+    ap.add_argument("--b", required=True)
+    ap.add_argument("--set", default="smooth13", choices=["smooth13", "primes"])
+    ap.add_argument("--sizes", default="")
+    ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--gib", type=float, default=0.5)
+    args = ap.parse_args()
+    dt, tdt, esz = (np.complex64, torch.complex64, 8) if args.dtype == "f32" else (np.complex128, torch.complex128, 16)
+    pl = [rustfft_amd.FftPlannerHip(dt, lib=_native.load(os.path.join(ROOT, "rustfft_amd", "lib", p))) for p in (args.a, args.b)]
+
+    def smooth(v):
+        for q in (2, 3, 5, 7, 11, 13):
+            while v % q == 0:
+                v //= q
+        return v == 1
+
+    if args.sizes:
+        sizes = [int(s) for s in args.sizes.split(",")]
+    elif args.set == "smooth13":
+        sizes = [v for v in range(3, 4097) if smooth(v) and (v & (v - 1))]
+    else:
+        sizes = [p for p in range(2, 4097) if all(p % q for q in range(2, int(p**0.5) + 1))]
+    x = torch.empty(int(args.gib * (1 << 30)) // esz, dtype=tdt, device="cuda")
+    torch.view_as_real(x).uniform_(-1.0, 1.0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for n in sizes:
+        batch = x.numel() // n
+        buf = x[: batch * n]
+        ffts = [p.plan_fft_forward(n) for p in pl]
+        if ffts[0].describe() == ffts[1].describe():
+            continue
+        for f in ffts:
+            f.process(buf)
+        best = [1e9, 1e9]
+        for _ in range(3):
+            for i, f in enumerate(ffts):
+                e0.record()
+                f.process(buf)
+                f.process(buf)
+                e1.record()
+                torch.cuda.synchronize()
+                best[i] = min(best[i], e0.elapsed_time(e1) / 2)
+            buf.mul_(1e-4)
+        tb = [batch * 2 * n * esz / (t * 1e-3) / 1e12 for t in best]
+        print(json.dumps({"n": n, "a_TBps": round(tb[0], 3), "b_TBps": round(tb[1], 3), "b_over_a": round(tb[1] / tb[0], 3),
+                          "plan_a": ffts[0].describe(), "plan_b": ffts[1].describe()}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
