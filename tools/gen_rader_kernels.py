@@ -23,8 +23,8 @@ NFILES = 4
 # Measured choices (profiles/r2/rader_ab1_*.json: every prime through the default choice and through "rows loop wherever it
 # can be instantiated", same box, 1 GiB of rows; a prime is listed when the alternative ran > 5 % faster):
 # f64 rows-loop bodies with the default schedule (the first five compile without scratch, the others spill 8 .. 100 bytes per
-# lane and still win)
-F64_ROWS = {727, 811, 991, 1459, 2801, 1201, 1297, 1373, 1621, 1783, 1801, 1951, 2081, 2251, 2593, 2663, 3169, 3457, 3697, 4051}
+# lane and still win; 1459 and 2801 compiled without scratch but lost 11 - 18 % in the one-process confirmation and are MODE 1 again)
+F64_ROWS = {727, 811, 991, 1201, 1297, 1373, 1621, 1783, 1801, 1951, 2081, 2251, 2593, 2663, 3169, 3457, 3697, 4051}
 # primes below ~800 whose default schedule has fewer than 64 threads per row: schedule_wide + the rows loop (1.1 - 2.3x)
 WIDE_ROWS = ({(32, p) for p in (193, 257, 271, 281, 331, 337, 353, 397, 401, 421, 433, 449, 463, 487, 491, 541, 577, 601, 617, 631, 641,
                                 661, 673, 769)} |
@@ -81,8 +81,10 @@ WIDE2_ROWS = ({(32, p) for p in (701, 727, 757, 881, 883, 1297)} |
 # primes whose p - 1 has a prime factor 17 .. 31 (schedule31: prime-radix sub-passes): 99 of them <= 4096; as Rader bodies most
 # lose to the one-kernel Bluestein (median 0.9x), these win by 7 - 59 % (profiles/r2/rader_ab3_*.json) -- mostly where
 # Bluestein has to pad 2p - 1 up to 5120 or 6144
-EXTRA31 = ({(32, p) for p in (137, 523, 571, 613, 647, 683, 2089, 2129, 2143, 2281, 2347, 2381, 2531, 2857)} |
-           {(64, p) for p in (571, 613, 647, 1123, 2053, 2129, 2143, 2281, 2393, 2437, 2531, 2843, 3469, 3571, 3673, 3877, 3911)})
+EXTRA31 = ({(32, p) for p in (137, 647, 683, 2089, 2143, 2857)} |
+           {(64, p) for p in (613, 2053, 2129, 2281, 2393, 2437, 2531, 2843, 3469, 3571, 3673, 3877, 3911)})
+# (the sweep listed 14 / 17; the Bluestein bodies were then rescheduled -- 1280 and 5120 run 22 % faster -- and the one-process
+# confirmation, profiles/r2/rader_choices_confirm_*.jsonl, kept the 6 / 13 that still win by > 3 %)
 # f32 bodies whose tables spill at MODE 2's 168 VGPRs and run 5 - 23 % faster at MODE 4's 256 (profiles/r2/rader_ab4_*.json; 1301
 # is the one spiller that loses 24 % and stays; the same run: the rows loop for the EXTRA31 primes loses 5 - 60 %)
 MODE4_F32 = {991, 1453, 2179, 2917, 2971, 4051}
