@@ -26,7 +26,8 @@ def main():
     else:
         planner = rustfft_amd.FftPlanner(dt)
     primes = [p for p in range(2, 4097) if all(p % q for q in range(2, int(p**0.5) + 1))]
-    if "--set" in sys.argv and sys.argv[sys.argv.index("--set") + 1] == "smooth13":  # every 13-smooth non-power-of-two length instead
+    smooth_set = "--set" in sys.argv and sys.argv[sys.argv.index("--set") + 1] == "smooth13"
+    if smooth_set:  # every 13-smooth non-power-of-two length instead
         def smooth(v):
             for q in (2, 3, 5, 7, 11, 13):
                 while v % q == 0:
@@ -54,7 +55,7 @@ def main():
             ts.append(e0.elapsed_time(e1) / 3)
             buf.mul_(1e-3)  # keep magnitudes bounded (unnormalised transforms grow by sqrt(p) per call)
         d = fft.describe()
-        fam = d.split(">")[1] if d.startswith("k1<") else "rader" if d.startswith("rader") or "dyn_rader" in d else "bluestein" if "bluestein" in d else "butterfly/mixed-radix"
+        fam = (d.split(">")[1] if smooth_set else "butterfly/mixed-radix") if d.startswith("k1<") else "rader" if d.startswith("rader") or "dyn_rader" in d else "bluestein" if "bluestein" in d else "butterfly/mixed-radix"
         rows.append([p, round(batch * 2 * p * esz / min(ts) / 1e9, 3), fam])
     summary = {}
     for fam in sorted(set(r[2] for r in rows)):
