@@ -4,6 +4,7 @@
 namespace mi355 {
 void register_k1_f32(std::vector<KernelEntry>& reg) {
     MI_K1_LIST(float, 32);
+    MI_K1(float, 32, 1, false, 4096, 256, 16, 16, 16);  // interleaved A/B: 5.08 TB/s against 4.82 for 8 x 8 x 8 x 8 on 512 threads
     // 2^13 .. 2^15 in ONE kernel: the real and imaginary planes go through LDS one after the other (split exchange), so a
     // whole 32768-point row fits 132 KB.  Measured on MI355X: 18.0 / 20.8 / 20.3 TFLOP/s (4.6 / 4.8 / 4.3 TB/s) against
     // 10.6 / 12.2 / 12.7 for two column-tile passes.  Variants: the 16-values-per-thread schedules (4.4 - 4.5 TB/s at 8192).
@@ -29,6 +30,19 @@ void register_k1_f32(std::vector<KernelEntry>& reg) {
     MI_BS2(float, 32, 1, true, 24576, 1024, 32, 32, 24);
     MI_BS2(float, 32, 1, true, 32768, 1024, 32, 32, 32);
     MI_K1V(4, float, 32, 1, true, 8192, 512, 16, 8, 8, 8);
+    // tuning: lighter sub-passes / more threads for the whole-row kernels (tools/ab.py --log2n k min:MI355FFT_VARIANT=v)
+    MI_K1V(5, float, 32, 1, false, 4096, 512, 8, 8, 8, 8);
+    MI_K1V(6, float, 32, 2, false, 4096, 256, 16, 16, 16);
+    // (profiles/r2/ab_k1_pow2_f32.jsonl: none of these beats the shipped whole-row schedules in f32)
+    MI_K1V(5, float, 32, 1, true, 8192, 512, 8, 8, 8, 16);
+    MI_K1V(6, float, 32, 1, false, 8192, 512, 16, 16, 32);
+    MI_K1V(7, float, 32, 1, false, 8192, 512, 8, 8, 8, 16);
+    MI_K1V(8, float, 32, 1, true, 8192, 1024, 8, 8, 8, 16);
+    MI_K1V(5, float, 32, 1, true, 16384, 1024, 8, 8, 16, 16);
+    MI_K1V(6, float, 32, 1, true, 16384, 1024, 16, 16, 8, 8);
+    MI_K1V(7, float, 32, 1, true, 16384, 512, 8, 8, 16, 16);
+    MI_K1V(5, float, 32, 1, true, 32768, 1024, 8, 16, 16, 16);
+    MI_K1V(6, float, 32, 1, true, 32768, 1024, 16, 16, 16, 8);
     // ablation probes of the 1024-point kernel (MI355FFT_VARIANT=5..7, wrong results by design): measured 5.36 TB/s for the
     // load/store skeleton against 5.1 - 5.2 TB/s for the full kernel.  Tuning history (no gain, removed): F = 2 / 8 rows per
     // workgroup, radix-8 schedules, 128-thread 4096 kernel, non-temporal loads/stores (tools/membench shows +11 % for an

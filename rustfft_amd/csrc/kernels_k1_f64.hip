@@ -4,10 +4,15 @@
 namespace mi355 {
 void register_k1_f64(std::vector<KernelEntry>& reg) {
     MI_K1_LIST(double, 64);
+    MI_K1(double, 64, 1, false, 4096, 512, 8, 8, 8, 8);  // interleaved A/B (profiles/r2/ab_k1_pow2_f64.jsonl): 5.25 TB/s against 5.00 for 16 x 16 x 16 on 256 threads
     // 2^13, 2^14 in one kernel (split exchange): 10.0 / 10.1 TFLOP/s (5.05 / 4.7 TB/s) against 5.8 / 6.1 for two passes
-    MI_K1(double, 64, 1, true, 8192, 512, 16, 8, 8, 8);
+    MI_K1(double, 64, 1, true, 8192, 512, 8, 8, 8, 16);  // 5.44 TB/s against 5.22 for 16 x 8 x 8 x 8
     MI_K1(double, 64, 1, true, 16384, 512, 16, 32, 32);
     MI_K1V(3, double, 64, 1, true, 16384, 1024, 16, 16, 8, 8);
+    MI_K1V(5, double, 64, 1, false, 4096, 256, 16, 16, 16);  // tuning: the schedules the two above replaced
+    MI_K1V(5, double, 64, 1, true, 8192, 512, 16, 8, 8, 8);
+    MI_K1V(6, double, 64, 1, true, 8192, 1024, 8, 8, 8, 16);
+    MI_K1V(5, double, 64, 1, true, 16384, 1024, 8, 8, 16, 16);
     // one-kernel Bluestein for 4096 < n <= 8192: split exchange, spectrum handed over in registers (960 GB/s at n = 4099 against
     // 800 for the two-kernel form it replaces)
     MI_BSS(double, 64, 1, 12288, 768, 16, 16, 16, 3);
