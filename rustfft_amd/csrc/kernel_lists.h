@@ -12,12 +12,8 @@
     MI_K1(T, PREC, 64, false, 16, 4, 4, 4);           \
     MI_K1(T, PREC, 64, false, 32, 4, 8, 4);           \
     MI_K1(T, PREC, 32, false, 64, 8, 8, 8);           \
-    MI_K1(T, PREC, 32, false, 128, 8, 16, 8);         \
-    MI_K1(T, PREC, 16, false, 256, 16, 16, 16);       \
-    MI_K1(T, PREC, 8, false, 512, 32, 16, 8, 4);      \
-    MI_K1(T, PREC, 4, false, 1024, 64, 16, 16, 4);    \
-    MI_K1(T, PREC, 2, false, 2048, 128, 16, 16, 8)
-// (4096 is registered per precision in kernels_k1_*.hip: f32 16 x 16 x 16 on 256 threads, f64 8 x 8 x 8 x 8 on 512)
+    MI_K1(T, PREC, 32, false, 128, 8, 16, 8)
+// (256 ... 4096 are registered per precision in kernels_k1_*.hip: their tilings are measured choices, tools/ab.py)
 
 
 // Bluestein bodies, one per inner power-of-two length M (serves every n with 2n - 1 <= M).  Workgroups of one wave (64

@@ -4,6 +4,23 @@
 namespace mi355 {
 void register_k1_f32(std::vector<KernelEntry>& reg) {
     MI_K1_LIST(float, 32);
+    // 256 ... 2048: one kernel per row block; the other tilings below (tuning entries) measured within 2 % of these
+    MI_K1(float, 32, 16, false, 256, 16, 16, 16);
+    MI_K1(float, 32, 8, false, 512, 32, 16, 8, 4);
+    MI_K1(float, 32, 4, false, 1024, 64, 16, 16, 4);
+    MI_K1(float, 32, 2, false, 2048, 128, 16, 16, 8);
+    // tuning: other tilings of the small whole-row kernels (tools/ab.py --log2n 8 .. 11 min:MI355FFT_VARIANT=v)
+    MI_K1V(5, float, 32, 8, false, 256, 32, 8, 8, 4);
+    MI_K1V(6, float, 32, 32, false, 256, 16, 16, 16);
+    MI_K1V(5, float, 32, 4, false, 512, 64, 8, 8, 8);
+    MI_K1V(6, float, 32, 8, false, 512, 64, 8, 8, 8);
+    MI_K1V(7, float, 32, 16, false, 512, 32, 16, 8, 4);
+    MI_K1V(5, float, 32, 2, false, 1024, 128, 8, 8, 16);
+    MI_K1V(6, float, 32, 8, false, 1024, 64, 16, 16, 4);
+    MI_K1V(7, float, 32, 4, false, 1024, 128, 16, 8, 8);
+    MI_K1V(5, float, 32, 1, false, 2048, 256, 8, 16, 16);
+    MI_K1V(6, float, 32, 4, false, 2048, 128, 16, 16, 8);
+    MI_K1V(7, float, 32, 1, false, 2048, 128, 16, 16, 8);
     MI_K1(float, 32, 1, false, 4096, 256, 16, 16, 16);  // interleaved A/B: 5.08 TB/s against 4.82 for 8 x 8 x 8 x 8 on 512 threads
     // 2^13 .. 2^15 in ONE kernel: the real and imaginary planes go through LDS one after the other (split exchange), so a
     // whole 32768-point row fits 132 KB.  Measured on MI355X: 18.0 / 20.8 / 20.3 TFLOP/s (4.6 / 4.8 / 4.3 TB/s) against
