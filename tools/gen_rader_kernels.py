@@ -88,6 +88,10 @@ EXTRA31 = ({(32, p) for p in (137, 647, 683, 2089, 2143, 2857)} |
 # f32 bodies whose tables spill at MODE 2's 168 VGPRs and run 5 - 23 % faster at MODE 4's 256 (profiles/r2/rader_ab4_*.json; 1301
 # is the one spiller that loses 24 % and stays; the same run: the rows loop for the EXTRA31 primes loses 5 - 60 %)
 MODE4_F32 = {991, 1453, 2179, 2917, 2971, 4051}
+F_TARGET = int(os.environ.get("RADER_F_TARGET", "256"))  # experiment knob: threads per workgroup of the rows-side-by-side bodies
+# (prec, p) -> rows per workgroup of the rows-side-by-side bodies (MODE 1) where half the rule's count ran > 4 % faster in a one-process
+# interleaved A/B of every prime (tools/ab_lengths.py --set primes, profiles/r2/rader_mode1_rows_ab_*.jsonl; twice the count loses 13 - 20 %)
+MODE1_ROWS = {(32, 37): 42, (32, 41): 32, (32, 43): 42, (32, 53): 32, (32, 61): 32, (32, 67): 21, (32, 73): 21, (32, 79): 18, (32, 113): 16, (32, 127): 9, (32, 197): 9, (32, 379): 3, (32, 521): 3, (32, 547): 3, (32, 677): 2, (64, 37): 42, (64, 41): 32, (64, 43): 42, (64, 53): 32, (64, 61): 32, (64, 67): 21, (64, 71): 25, (64, 73): 21, (64, 79): 18, (64, 97): 16, (64, 109): 10, (64, 113): 16, (64, 163): 7, (64, 197): 9, (64, 199): 7, (64, 271): 4, (64, 521): 3, (64, 547): 3, (64, 617): 2, (64, 661): 2}
 ALT = os.environ.get("RADER_ALT") == "1"  # experiment 1: the rows loop wherever it can be instantiated (A/B against the default choice)
 ALT2 = os.environ.get("RADER_ALT") == "2"  # experiment 2: one butterfly per thread, smallest radices, for the primes with >= 64 threads per row
 
@@ -127,7 +131,9 @@ def choose(p, prec):
         return (8, 3, rad, tpf)
     if prec == 32 and tpf >= 64 and nreg <= 118:  # tables up to 256 VGPRs, two waves per SIMD
         return (8, 4, rad, tpf)
-    f = max(1, min(256 // tpf, (60 * 1024) // (pitch * esz)))
+    f = max(1, min(F_TARGET // tpf, (60 * 1024) // (pitch * esz)))
+    if (prec, p) in MODE1_ROWS:
+        f = MODE1_ROWS[(prec, p)]
     if xs < pitch and p <= pitch:
         return (f, 1, rad, tpf)
     f = max(1, min(256 // tpf, (60 * 1024) // ((pitch + p) * esz)))
