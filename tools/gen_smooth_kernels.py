@@ -81,6 +81,7 @@ def schedule_small_radix(n):
 
 
 SCHED_ALT = os.environ.get("SMOOTH_SCHED_ALT") == "1"
+ROWS31_TARGET = int(os.environ.get("SMOOTH_ROWS31_TARGET", "256"))  # experiment knob for the prime-radix schedules (main_primes)
 ROWS_TARGET = int(os.environ.get("SMOOTH_ROWS_TARGET", "256"))  # experiment knob: threads per workgroup the row count aims at
 
 
@@ -210,7 +211,11 @@ def main_primes(limits=(("f32", "float", 32, 8, 4096, 14), ("f64", "double", 64,
             lines = []
             for n in sizes[ci::nfiles]:
                 rad, tpf = schedule31(n)
-                f = max(1, min(256 // tpf, (48 * 1024) // ((n + n // 8 + 2) * esz)))  # <= 256 threads: the prime butterflies want > 128 VGPRs
+                f = max(1, min(ROWS31_TARGET // tpf, (48 * 1024) // ((n + n // 8 + 2) * esz)))  # <= 256 threads: the prime butterflies want > 128 VGPRs
+                # half the rows where a one-process interleaved A/B of every length measured > 4 % (profiles/r2/prime_radix_rows_ab_*.jsonl:
+                # 113 of 389 changed f32 lengths, 36 of 89 f64; the median over all of them is 0.99 / 1.02, so the rule stays)
+                if ROWS31_TARGET == 256 and str(n) in _CHOICES.get("rows31", {}).get(tag, {}):
+                    f = _CHOICES["rows31"][tag][str(n)]
                 lines.append(f"    MI_K1({ty}, {prec}, {f}, false, {n}, {tpf}, {', '.join(map(str, rad))});")
             path = os.path.join(ROOT, "rustfft_amd", "csrc", f"kernels_smooth3_{tag}_{ci}.hip")
             with open(path, "w") as fh:
