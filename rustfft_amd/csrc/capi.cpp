@@ -67,6 +67,9 @@ int process_host(const mi355fft_plan* cplan, const void* in, size_t n_in, void* 
         if (!in || !out) return set_err(MI355FFT_ERR_INVALID_ARG, "null buffer");
         const size_t esz = plan.prec == 32 ? 8 : 16;
         const size_t bytes = batch * len * esz;
+        // staging buffers, copies and the final sync all belong to the plan's device, whatever device is current in the
+        // calling thread (a fresh thread defaults to device 0)
+        DeviceGuard dev(plan.device);
         std::lock_guard<std::mutex> g(plan.host_mutex);
         void* d_in = stage(plan.stage_a, bytes);
         void* d_out = mode == 0 ? d_in : stage(plan.stage_b, bytes);

@@ -58,6 +58,22 @@ template <class T> MI_HD cx<T> operator*(cx<T> a, cx<T> b) {
     return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
 }
 template <class T> MI_HD cx<T> operator*(cx<T> a, T s) { return {a.re * s, a.im * s}; }
+#if defined(__HIP_DEVICE_COMPILE__) && defined(MI355_PK)
+// EXPERIMENT: Complex<float> arithmetic as <2 x float> vector operations (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32)
+typedef float mi_v2f __attribute__((ext_vector_type(2)));
+MI_HD cx<float> operator+(cx<float> a, cx<float> b) {
+    mi_v2f r = mi_v2f{a.re, a.im} + mi_v2f{b.re, b.im};
+    return {r.x, r.y};
+}
+MI_HD cx<float> operator-(cx<float> a, cx<float> b) {
+    mi_v2f r = mi_v2f{a.re, a.im} - mi_v2f{b.re, b.im};
+    return {r.x, r.y};
+}
+MI_HD cx<float> operator*(cx<float> a, float s) {
+    mi_v2f r = mi_v2f{a.re, a.im} * mi_v2f{s, s};
+    return {r.x, r.y};
+}
+#endif
 template <class T> MI_HD cx<T> cconj(cx<T> a) { return {a.re, -a.im}; }
 // multiply by -i (forward quarter turn; the reference's rotate_90, src/twiddles.rs:59-70)
 template <class T> MI_HD cx<T> mul_neg_i(cx<T> a) { return {a.im, -a.re}; }

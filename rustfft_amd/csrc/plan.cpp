@@ -174,20 +174,6 @@ template <class T> static std::vector<T> build_subpass_twiddles(const KernelEntr
     return t;
 }
 
-// RAII: make the plan's device current for the calling thread (HIP's current device is per thread and defaults to 0)
-struct DeviceGuard {
-    int prev = -1;
-    bool switched = false;
-    explicit DeviceGuard(int want) {
-        if (want < 0) return;
-        prev = backend::current_device();
-        if (prev != want && backend::set_device(want) == 0) switched = true;
-    }
-    ~DeviceGuard() {
-        if (switched && prev >= 0) backend::set_device(prev);
-    }
-};
-
 Plan::~Plan() {
     // asynchronous launches may still be reading the tables / workspaces: drain the device (not the cached stream
     // handles -- the caller may have destroyed those streams already)
@@ -983,16 +969,23 @@ void* Plan::workspace_in(StreamSlot& slot, size_t bytes, void* stream) {
     return w.ptr;
 }
 size_t Plan::workspace_bytes() {
-    std::lock_guard<std::mutex> g(ws_mutex);
+    std::vector<StreamSlot*> all;
+    {
+        std::lock_guard<std::mutex> g(ws_mutex);
+        for (auto& kv : slots) all.push_back(kv.second.get());
+    }
     size_t total = 0;
-    for (auto& kv : slots) total += kv.second->ws.bytes;
+    for (StreamSlot* s : all) {  // ws.bytes changes under the slot's launch lock (workspace_in)
+        std::lock_guard<std::mutex> g(s->launch_mutex);
+        total += s->ws.bytes;
+    }
     return total + (inner ? inner->workspace_bytes() : 0);
 }
-// Releases every cached workspace (the map of slots stays).  Waits for the device first: the streams the slots were
-// used on may be gone, and launches that still read a workspace must finish before it is freed.
+// Releases every cached workspace (the map of slots stays).  Per slot: take the launch lock FIRST (no caller can enqueue a
+// pass that uses the workspace from here on), then drain the device (the stream the slot was used on may be gone; launches
+// already enqueued must finish before their workspace is freed), then free.
 size_t Plan::trim_workspaces() {
     DeviceGuard dev(device);
-    backend::sync_device();
     size_t freed = inner ? inner->trim_workspaces() : 0;
     std::vector<StreamSlot*> all;
     {
@@ -1001,6 +994,8 @@ size_t Plan::trim_workspaces() {
     }
     for (StreamSlot* s : all) {
         std::lock_guard<std::mutex> g(s->launch_mutex);
+        if (!s->ws.ptr) continue;
+        backend::sync_device();
         freed += s->ws.bytes;
         backend::dfree(s->ws.ptr);
         s->ws = Workspace{};

@@ -8,9 +8,26 @@
 
 #include "../../include/mi355fft.h"
 #include "dyn_engine.h"
+#include "backend.h"
 #include "registry.h"
 
 namespace mi355 {
+
+// RAII: make the plan's device current for the calling thread (HIP's current device is per thread and defaults to 0)
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int want) {
+        if (want < 0) return;
+        prev = backend::current_device();
+        if (prev != want && backend::set_device(want) == 0) switched = true;
+    }
+    ~DeviceGuard() {
+        if (switched && prev >= 0) backend::set_device(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 enum PlanKind { PLAN_TRIVIAL = 0, PLAN_SINGLE = 1, PLAN_MACRO = 2, PLAN_BLUESTEIN = 3, PLAN_RADER = 4, PLAN_BLUESTEIN_LARGE = 5, PLAN_BLUESTEIN_FUSED = 6, PLAN_BLUESTEIN_2K = 7 };
 

@@ -70,6 +70,9 @@ def scatter_rows(full, n, batch, dist, root=0, device=None, dtype=None):
     lo, hi = shard_rows(batch, world, rank)
     if rank == root:
         device, dtype = full.device, full.dtype
+    elif device is None or dtype is None:
+        # torch.empty(dtype=None, device=None) would silently make a CPU float32 buffer of half the bytes the root sends
+        raise ValueError("scatter_rows: ranks other than the root must pass the shard's device and dtype")
     local = torch.empty((hi - lo) * n, dtype=dtype, device=device)
     ops = []
     if rank == root:

@@ -101,3 +101,88 @@ def build_cpp_mirror_check():
                            "-L" + os.path.join(root, "rustfft_amd", "lib"), "-lmi355fft",
                            "-Wl,-rpath," + os.path.join(root, "rustfft_amd", "lib")])
     return exe
+
+
+def check_host_planner_options(planner, oracle):
+    """mi355fft_plan_create_ex (include/mi355fft.h): the host planner names the Recipe family, supplies its own
+    compute_twiddle (src/twiddles.rs:6-23) and / or its finished Rader / Bluestein tables (raders_algorithm.rs:87-113,
+    bluesteins_algorithm.rs:63-98).  Results must equal the default plan's bit for bit when the host's values are the
+    library's own, and follow the host's values when they differ."""
+    import pytest
+
+    import rustfft_amd
+
+    dtype = np.complex64
+    calls = []
+
+    def twiddle(index, fft_len):
+        calls.append((index, fft_len))
+        return oracle.compute_twiddle(dtype, index, fft_len, 0)  # the reference's own function, forward direction
+
+    for n in (1024, 1200, 1 << 16, 1009, 719):
+        x = random_signal(2 * n, dtype)
+        want = x.copy()
+        planner.plan_fft(n, 1).process(want)
+        calls.clear()
+        fft = planner.plan_fft_with(n, 1, twiddle_fn=twiddle)
+        assert calls and all(i < 2 * l + 1 for i, l in calls), n
+        got = x.copy()
+        fft.process(got)
+        if n in (1024, 1200, 1 << 16):
+            assert np.array_equal(got, want), n  # oracle twiddles == library twiddles (both f64 angle, cos/sin, rounded to T)
+        else:  # Rader / Bluestein precompute spectra FROM the twiddles: host values rounded to T move them by ~eps
+            assert rel_l2(got, want) < 2e-6 and not np.array_equal(got, want), n
+    # a host twiddle function that is deliberately different shows the tables really come from it
+    fft = planner.plan_fft_with(4096, 0, twiddle_fn=lambda i, l: 1.0 + 0.0j)
+    y = random_signal(4096, dtype)
+    z = y.copy()
+    fft.process(z)
+    ref = y.copy()
+    planner.plan_fft(4096, 0).process(ref)
+    assert not np.allclose(z, ref)
+
+    # algorithm families
+    assert "bluestein" in planner.plan_fft_with(1024, 0, algorithm=rustfft_amd.ALGO_BLUESTEIN).describe()
+    assert "k1<" in planner.plan_fft_with(1024, 0, algorithm=rustfft_amd.ALGO_MIXED_RADIX).describe()
+    with pytest.raises(rustfft_amd.FftPanic, match="no GPU plan"):
+        planner.plan_fft_with(1019, 0, algorithm=rustfft_amd.ALGO_MIXED_RADIX)  # prime, 1018 = 2 * 509: nothing direct
+    with pytest.raises(rustfft_amd.FftPanic, match="no GPU plan"):
+        planner.plan_fft_with(1019, 0, algorithm=rustfft_amd.ALGO_RADER)  # 509 is not 13-smooth
+    x = random_signal(3 * 1024, dtype)
+    a, b = x.copy(), x.copy()
+    planner.plan_fft_with(1024, 0, algorithm=rustfft_amd.ALGO_BLUESTEIN).process(a)
+    oracle.plan(dtype, 1024, 0).process(b)
+    assert compare_vectors(a, b)
+
+    # finished tables from the reference's own algorithm objects (here: the oracle restating them), both directions
+    for d in (0, 1):
+        # Bluestein: twiddles[n] and inner_fft_multiplier[M] exactly as bluesteins_algorithm.rs:63-98 builds them
+        n = 719
+        M = planner.bluestein_inner_len(n)
+        assert M >= 2 * n - 1
+        tw = np.array([oracle.compute_twiddle(dtype, (i * i) % (2 * n), 2 * n, d) for i in range(n)], dtype=dtype)
+        mult = np.zeros(M, dtype=dtype)
+        mult[0] = np.conj(tw[0]) / M
+        for i in range(1, n):
+            mult[i] = mult[M - i] = np.conj(tw[i]) / M
+        inner = oracle.plan(dtype, M, d)
+        inner.process(mult)
+        fft = planner.plan_fft_with(n, d, algorithm=rustfft_amd.ALGO_BLUESTEIN, bluestein_twiddles=tw, bluestein_multiplier=mult)
+        check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=3)
+        with pytest.raises(rustfft_amd.FftPanic, match="host tables do not fit"):
+            planner.plan_fft_with(n, d, algorithm=rustfft_amd.ALGO_BLUESTEIN, bluestein_twiddles=tw, bluestein_multiplier=mult[: M // 2])
+        # Rader: inner_fft_data[p - 1] as raders_algorithm.rs:87-113 builds it (smallest primitive root, unity / (p-1))
+        p = 1009
+        g = oracle.primitive_root(p)
+        ginv = pow(g, p - 2, p)
+        data = np.zeros(p - 1, dtype=dtype)
+        t = 1
+        for j in range(p - 1):
+            data[j] = oracle.compute_twiddle(dtype, t, p, d) / (p - 1)
+            t = t * ginv % p
+        oracle.plan(dtype, p - 1, d).process(data)
+        fft = planner.plan_fft_with(p, d, algorithm=rustfft_amd.ALGO_RADER, rader_inner_fft_data=data)
+        assert "rader" in fft.describe()
+        check_fft_algorithm(fft, p, d, reference=oracle.plan(dtype, p, d), n=3)
+    with pytest.raises(rustfft_amd.FftPanic, match="needs algorithm"):
+        planner.plan_fft_with(1009, 0, rader_inner_fft_data=np.zeros(1008, dtype=dtype))

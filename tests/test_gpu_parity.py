@@ -644,3 +644,107 @@ def test_repeatability_bit_for_bit(planners):
                     first = y
                 else:
                     assert torch.equal(torch.view_as_real(first), torch.view_as_real(y)), (n, np.dtype(dtype).name, fft.describe())
+
+
+@pytest.mark.parametrize("dtype,log2n", [(np.complex64, 23), (np.complex64, 24), (np.complex128, 23)])
+def test_three_pass_pow2_plans(planners, oracle, dtype, log2n):
+    """The three-kernel power-of-two plans (2^23, 2^24; north_star's range ends at 2^24, SURVEY section 8 a15 names "2^24 k=10"):
+    both directions, two HBM-resident rows, against the oracle's Radix4 (src/algorithm/radix4.rs:167-203) under the
+    reference tolerance and against numpy complex128."""
+    import torch
+
+    n, batch = 1 << log2n, 2
+    planner = planners[np.dtype(dtype)]
+    x = random_signal(n * batch, dtype, seed=log2n)
+    for d in (0, 1):
+        fft = planner.plan_fft(n, d)
+        assert fft.describe().count("k2") == 3, fft.describe()
+        y = torch.from_numpy(x).cuda()
+        fft.process(y)
+        torch.cuda.synchronize()
+        got = y.cpu().numpy()
+        want = x.copy()
+        oracle.plan(dtype, n, d).process(want)
+        assert compare_vectors(want, got), (log2n, d)
+        assert rel_l2(got, numpy_fft(x, n, d == 1)) < REL[np.dtype(dtype)], (log2n, d)
+        # the out-of-place device entry point runs the same three passes through other buffers: bit-identical
+        a = torch.from_numpy(x).cuda()
+        out = torch.empty_like(a)
+        fft.process_immutable_with_scratch(a, out)
+        assert torch.equal(torch.view_as_real(out), torch.view_as_real(y)), (log2n, d)
+
+
+def test_host_planner_options_on_device(planners, oracle):
+    """mi355fft_plan_create_ex on the real device -- the "planner / twiddle host code stays in Rust" half of the boundary: the
+    oracle plays the Rust planner and supplies compute_twiddle (src/twiddles.rs:6-23), RadersAlgorithm::new's inner_fft_data
+    (raders_algorithm.rs:87-113) and BluesteinsAlgorithm::new's twiddles + multiplier (bluesteins_algorithm.rs:63-98)."""
+    from helpers import check_host_planner_options
+
+    check_host_planner_options(planners[np.dtype(np.complex64)], oracle)
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_large_primes_vs_oracle(planners, oracle, dtype):
+    """Primes above one workgroup's reach with a smooth p - 1 (the reference plans RadersAlgorithm for them, src/plan.rs:636-665;
+    raders_algorithm.rs:302-322 tests 112501 / 216569 / 417623 the same way): all four API modes against the oracle's plan and
+    numpy complex128, both directions."""
+    planner = planners[np.dtype(dtype)]
+    for p in (12289, 40961, 65537, 112501):
+        for d in (0, 1):
+            fft = planner.plan_fft(p, d)
+            check_fft_algorithm(fft, p, d, reference=oracle.plan(dtype, p, d), n=2)
+            x = zero_mean_signal(p * 3, dtype, seed=p)
+            y = x.copy()
+            fft.process(y)
+            assert rel_l2(y, numpy_fft(x, p, d == 1)) < REL[np.dtype(dtype)], (p, d, fft.describe())
+
+
+def test_config2_full_batch_every_row(planners):
+    """BASELINE config 2 at its full size, every row: per-row Parseval (a mis-twiddled row keeps its element sum but not its
+    energy spectrum's consistency with a second check) and 64 rows drawn at random over the whole batch against numpy
+    complex128 -- forward and inverse."""
+    import torch
+
+    n, batch = 1 << 20, 1024
+    planner = planners[np.dtype(np.complex64)]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x52555354 + 222)
+    x = torch.empty(batch * n, dtype=torch.complex64, device="cuda")
+    torch.view_as_real(x).uniform_(-1.0, 1.0, generator=g)
+    rows = sorted(int(r) for r in np.random.default_rng(22).choice(batch, 64, replace=False))
+    keep = {r: x[r * n:(r + 1) * n].cpu().numpy() for r in rows}
+
+    def energy(t):
+        v = torch.view_as_real(t).view(batch, -1)
+        return torch.cat([(v[r0:r0 + 64].double() ** 2).sum(dim=1) for r0 in range(0, batch, 64)])
+
+    for d in (0, 1):
+        y = x.clone()
+        e_in = energy(y)
+        planner.plan_fft(n, d).process(y)
+        torch.cuda.synchronize()
+        rel = ((energy(y) / n - e_in).abs() / e_in).max().item()
+        assert rel < 1e-5, (d, rel)
+        for r in rows:
+            got = y[r * n:(r + 1) * n].cpu().numpy()
+            assert rel_l2(got, numpy_fft(keep[r], n, d == 1)) < REL[np.dtype(np.complex64)], (d, r)
+        del y
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """Multi-GPU readiness on a one-GPU box: `bench.py --gpus 2` self-spawns two ranks (torchrun's environment contract) that
+    share cuda:0 and rendezvous over gloo; barrier + MAX-over-ranks timing, the per-rank checks MAX-reduced, the nested
+    config-5 measurement and the scatter / gather edges all run end to end.  (The RCCL path differs only in the backend name.)"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--one-device", "--dist-backend", "gloo", "--steps", "2",
+                        "--warmup", "1", "--batch", "64", "--edges", "--no-pmc", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert "FAILED" not in line["check"] and line["check"]["roundtrip_rel_l2"] < 5e-6
+    assert line["config5"]["parseval_max_rel_err_over_ranks"] < 1e-4
+    assert line["edges"]["scatter_s"] > 0
