@@ -359,22 +359,67 @@ template <class S, int P, Map MIN, Map MOUT> constexpr Map pass_map() {
     return P == 0 ? MIN : (P == S::NP - 1 ? MOUT : MAP_EF);
 }
 
+// register array length an executor must provide per thread
+template <class S, bool SPLIT> constexpr int regs_needed() { return S::emax(); }
+// LDS bytes one workgroup needs
+template <class T, class S, int F, bool SPLIT, int PM = 1> constexpr size_t lds_bytes() {
+    return (S::NP > 1) ? (size_t)F * S::template pitch_for<PM>() * (SPLIT ? sizeof(T) : sizeof(cx<T>)) : 0;
+}
+
+// ---- sub-pass twiddle tables staged in LDS (TWL) ----------------------------------------------------------------------
+// TWL is a bit mask of sub-passes (bit p = sub-pass p >= 1; the set bits must be contiguous) whose twiddle tables the
+// workgroup copies from global memory into LDS, behind its exchange buffer, while its first loads are in flight: the table
+// loads are issued in front of the first row loads and written to LDS behind them (loads return in order, so the writes
+// wait for the table entries only), and the barriers of the first exchange publish the copy before sub-pass 1 reads it.
+// Why: a sub-pass fetches its factors right after a barrier.  As global loads they queue in the CU's vector-memory pipeline
+// behind the co-resident workgroups' row bursts (128 KiB each for the column tiles), and their latency -- microseconds under
+// load -- is exposed once per sub-pass; ds_read_b64 from LDS comes back in ~100 cycles whatever HBM is doing
+// (measured on the 1024 x 16 column tiles of 2^20: first pass 5.41 -> 5.60 TB/s, later pass 5.10 -> 5.52, results bit-identical).
+template <class S> constexpr int tw_pass_entries(int p) { return (p >= 1 && p < S::NP) ? (S::R[p] - 1) * S::stride(p) : 0; }
+template <class S> constexpr int twl_first(int mask) {
+    for (int p = 1; p < S::NP; ++p)
+        if ((mask >> p) & 1) return p;
+    return S::NP;
+}
+template <class S> constexpr int twl_total(int mask) {
+    int o = 0;
+    for (int p = 1; p < S::NP; ++p)
+        if ((mask >> p) & 1) o += tw_pass_entries<S>(p);
+    return o;
+}
+template <class S> constexpr bool twl_valid(int mask) {  // contiguous run of sub-passes >= 1
+    if (mask == 0) return true;
+    if (mask & 1) return false;
+    int m = mask >> twl_first<S>(mask);
+    return (m & (m + 1)) == 0 && (mask >> S::NP) == 0;
+}
+constexpr int twl_all(int np) { return ((1 << np) - 1) & ~1; }
+constexpr size_t align16(size_t b) { return (b + 15) & ~(size_t)15; }
+// LDS bytes one workgroup needs, staged tables included
+template <class T, class S, int F, bool SPLIT, int PM = 1, int TWL = 0> constexpr size_t lds_bytes_twl() {
+    return TWL ? align16(lds_bytes<T, S, F, SPLIT, PM>()) + (size_t)twl_total<S>(TWL) * sizeof(cx<T>) : lds_bytes<T, S, F, SPLIT, PM>();
+}
+
 // ---- the workgroup transform -------------------------------------------------------------------------
 // X: executor. X::for_threads(fn(tid, cx<T>* v)) runs fn for every thread of the workgroup with that
 //    thread's private register array; X::barrier() is the workgroup barrier.
 // src(f, i) -> cx<T>: input element i of sequence f;   dst(f, i, value): output element i.
 // ABL (compile-time, tuning builds only): bit 2 skips the arithmetic, bit 3 skips the LDS exchange — ablation probes
 // that keep the HBM access pattern; production instantiations use ABL = 0.
-template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, int PM, int ABL, int P, int TWREG = -1, bool TWSTAGE = false, class X, class SRC, class DST>
+template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, int PM, int ABL, int P, int TWREG = -1, bool TWSTAGE = false, int TWL = 0, class X, class SRC, class DST>
 MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& src, DST& dst) {
     constexpr int R = S::R[P], NB = S::nb(P), ST = S::stride(P), BPT = S::bpt(P);
     constexpr Map MP = pass_map<S, P, MIN, MOUT>();
     constexpr bool LAST = (P == S::NP - 1);
+    // this sub-pass's factors: the global table, or its LDS copy (compute_pass adds S::tw_offset(P) to whatever it is given)
+    const cx<T>* twp = tw;
+    if constexpr (((TWL >> P) & 1) != 0)
+        twp = (const cx<T>*)((char*)lds_raw + align16(lds_bytes<T, S, F, SPLIT, PM>())) - S::tw_offset(twl_first<S>(TWL));
     // arithmetic of pass P, then either the final store or the scatter half of the exchange
     ex.for_threads([&](int tid, cx<T>* v) {
         int f, u;
         map_tid<MP, F, S::TPF>(tid, f, u);
-        if constexpr (!(ABL & 4)) compute_pass<T, S, P, TWREG>(v, u, tw);
+        if constexpr (!(ABL & 4)) compute_pass<T, S, P, TWREG>(v, u, twp);
         if constexpr (LAST && std::is_same<DST, KeepInRegs>::value) {
         } else if constexpr (LAST) {
             static_for<0, BPT>([&](auto M_) {
@@ -401,7 +446,7 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
         }
     });
     if constexpr (!LAST && (ABL & 8) != 0) {
-        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, P + 1, TWREG, TWSTAGE>(ex, lds_raw, tw, src, dst);
+        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, P + 1, TWREG, TWSTAGE, TWL>(ex, lds_raw, tw, src, dst);
     } else if constexpr (!LAST) {
         constexpr Map MQ = pass_map<S, P + 1, MIN, MOUT>();
         ex.barrier();
@@ -436,7 +481,7 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
             });
             ex.barrier();
         }
-        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, P + 1, TWREG, TWSTAGE>(ex, lds_raw, tw, src, dst);
+        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, P + 1, TWREG, TWSTAGE, TWL>(ex, lds_raw, tw, src, dst);
     }
 }
 
@@ -460,24 +505,28 @@ template <class L> MI_HD ElemSrc<L> elem_src(L l) { return ElemSrc<L>{l}; }
 template <class SRC, class = void> struct src_loads_all : std::false_type {};
 template <class SRC> struct src_loads_all<SRC, std::enable_if_t<SRC::kLoadsAll>> : std::true_type {};
 
-// register array length an executor must provide per thread
-template <class S, bool SPLIT> constexpr int regs_needed() { return S::emax(); }
-// LDS bytes one workgroup needs
-template <class T, class S, int F, bool SPLIT, int PM = 1> constexpr size_t lds_bytes() {
-    return (S::NP > 1) ? (size_t)F * S::template pitch_for<PM>() * (SPLIT ? sizeof(T) : sizeof(cx<T>)) : 0;
-}
-
 // SRC_IN_LDS: `src` reads the same LDS buffer the exchanges use (Rader/Bluestein second transform), so a
 // barrier separates the loads from the first scatter.
-template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, bool SRC_IN_LDS = false, int PM = 1, int ABL = 0, int TWREG = -1, bool TWSTAGE = false, class X, class SRC, class DST>
+template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, bool SRC_IN_LDS = false, int PM = 1, int ABL = 0, int TWREG = -1, bool TWSTAGE = false, int TWL = 0, class X, class SRC, class DST>
 MI_HD void wg_fft(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC src, DST dst) {
     static_assert(S::valid(), "radices must multiply to N");
     static_assert(MIN != MAP_FFP || (pair_fusable<S>() && !SRC_IN_LDS && TWREG < 0 && sizeof(T) == 4), "the paired map is the pair-fused path");
+    static_assert(TWL == 0 || (twl_valid<S>(TWL) && !SRC_IN_LDS && TWREG < 0 && MIN != MAP_FFP && S::NP >= 2), "staged tables: plain transforms whose first exchange publishes the copy");
     constexpr int R0 = S::R[0], NB0 = S::nb(0), BPT0 = S::bpt(0);
+    constexpr int TWN = twl_total<S>(TWL), NT = F * S::TPF, TWPT = (TWN + NT - 1) / NT, TWSRC = S::tw_offset(twl_first<S>(TWL));
+    cx<T>* twl = (cx<T>*)((char*)lds_raw + align16(lds_bytes<T, S, F, SPLIT, PM>()));
     // inputs of sub-pass 0 straight from the source
     ex.for_threads([&](int tid, cx<T>* v) {
         int f, u;
         map_tid<MIN, F, S::TPF>(tid, f, u);
+        cx<T> twr[TWPT > 0 ? TWPT : 1];
+        if constexpr (TWN > 0) {
+            static_for<0, TWPT>([&](auto I_) {
+                constexpr int i = I_;
+                const int e = tid + i * NT;
+                twr[i] = tw[TWSRC + (((i + 1) * NT <= TWN || e < TWN) ? e : 0)];
+            });
+        }
         if constexpr (src_loads_all<SRC>::value) {
             src.template load_all<S>(f, u, v);
         } else {
@@ -488,6 +537,13 @@ MI_HD void wg_fft(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC src, DS
                     src.template bfly<R0>(f, b, NB0, v + m * R0);
                 }
                 if constexpr (BPT0 > 1 && R0 * BPT0 > 16) MI_SCHED_FENCE();
+            });
+        }
+        if constexpr (TWN > 0) {
+            static_for<0, TWPT>([&](auto I_) {
+                constexpr int i = I_;
+                const int e = tid + i * NT;
+                if ((i + 1) * NT <= TWN || e < TWN) twl[e] = twr[i];
             });
         }
     });
@@ -538,9 +594,9 @@ MI_HD void wg_fft(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC src, DS
             });
             ex.barrier();
         }
-        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, 2, TWREG, TWSTAGE>(ex, lds_raw, tw, src, dst);
+        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, 2, TWREG, TWSTAGE, TWL>(ex, lds_raw, tw, src, dst);
     } else {
-        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, 0, TWREG, TWSTAGE>(ex, lds_raw, tw, src, dst);
+        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, 0, TWREG, TWSTAGE, TWL>(ex, lds_raw, tw, src, dst);
     }
 }
 

@@ -20,6 +20,11 @@
 
 namespace mi355 {
 
+// ABL bits 7, 10, 11 (128 / 1024 / 2048; production options): sub-pass twiddle tables staged in LDS (engine.h TWL) -- all of
+// them / sub-pass 1 only / the last sub-pass only
+template <int ABL, int NP> constexpr int k1_twl() {
+    return NP < 2 ? 0 : (ABL & 128) ? twl_all(NP) : (ABL & 1024) ? 2 : (ABL & 2048) ? (1 << (NP - 1)) : 0;
+}
 template <class T, class S, int F, bool SPLIT, int ABL = 0, class X>
 MI_HD void k1_body(X& ex, const K1Params<T>& p, long long block, void* lds) {
     const long long fft0 = block * F;
@@ -49,7 +54,10 @@ MI_HD void k1_body(X& ex, const K1Params<T>& p, long long block, void* lds) {
                 out[(unsigned)(f * S::N + i)] = x;
         }
     };
-    wg_fft<T, S, F, MAP_EF, MAP_EF, SPLIT, false, 1, (ABL & 15)>(ex, lds, p.tw, elem_src(src), dst);
+    wg_fft<T, S, F, MAP_EF, MAP_EF, SPLIT, false, 1, (ABL & 15), -1, false, k1_twl<ABL, S::NP>()>(ex, lds, p.tw, elem_src(src), dst);
+}
+template <class T, class S, int F, bool SPLIT, int ABL> constexpr size_t k1_lds_bytes() {
+    return lds_bytes_twl<T, S, F, SPLIT, 1, k1_twl<ABL, S::NP>()>();
 }
 
 // ---- two-kernel Bluestein for lengths whose padded size M still fits ONE workgroup through the split exchange ------
@@ -106,7 +114,12 @@ constexpr int k2_pitch_mod(int f) { return f < 32 ? 32 / f : 1; }
 // error ~ sqrt of that times eps), six table gathers per thread.  (History: 2 R divergent gathers per butterfly ran the
 // later passes at 3.3 TB/s; base + step per butterfly with a depth-first power walk -- 16 gathers per thread -- at
 // 4.4 - 4.8; divergent 8-byte gathers cost the L1 one cycle per lane, the row segments one per 16 lanes.)
-template <class T, bool FIRST, int ABL = 0> struct K2Src {
+// ABL bits 7, 10, 11 (128 / 1024 / 2048; production options): the sub-pass twiddle tables of the tile transform are staged in
+// LDS (engine.h TWL) -- all of them / sub-pass 1 only / the last sub-pass only (for tiles whose LDS budget holds one table).
+template <int ABL, int NP> constexpr int k2_twl() {
+    return (ABL & 128) ? twl_all(NP) : (ABL & 1024) ? 2 : (ABL & 2048) ? (1 << (NP - 1)) : 0;
+}
+template <class T, bool FIRST, int ABL = 0, int F_ = 0> struct K2Src {
     static constexpr bool kLoadsAll = true;
     const cx<T>* in;  // no restrict: the in-place last pass reads and writes the caller's buffer
     unsigned M, b0, bmod0;
@@ -187,7 +200,7 @@ MI_HD void k2_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     const unsigned bdiv = FIRST ? 0u : (b0 >> p.s_shift);
     const unsigned bmod0 = FIRST ? 0u : (b0 & (s32 - 1u));
     const unsigned obase = bdiv * s32 * (unsigned)R + bmod0;
-    K2Src<T, FIRST, ABL> src{in, M, b0, bmod0, p.sgn_in, p.tlo, p.thi, p.hshift, p.lmask};
+    K2Src<T, FIRST, ABL, F> src{in, M, b0, bmod0, p.sgn_in, p.tlo, p.thi, p.hshift, p.lmask};
     auto dst = [=](int f, int k, cx<T> x) {
         x.im *= sgn_out;
         cx<T>* o = FIRST ? out + ((b0 + (unsigned)f) * (unsigned)R + (unsigned)k) : out + (obase + (unsigned)f + (unsigned)k * s32);
@@ -198,7 +211,11 @@ MI_HD void k2_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     };
     // first pass: lanes walk across the tile's columns on the way in and along each sequence on the way
     // out (the F*R output block is contiguous); later passes: across columns both ways
-    wg_fft<T, S, F, (ABL & 64) ? MAP_FFP : MAP_FF, FIRST ? MAP_EF : MAP_FF, SPLIT, false, k2_pitch_mod(F), (ABL & 15)>(ex, lds, p.tw, src, dst);
+    wg_fft<T, S, F, (ABL & 64) ? MAP_FFP : MAP_FF, FIRST ? MAP_EF : MAP_FF, SPLIT, false, k2_pitch_mod(F), (ABL & 15), -1, false, k2_twl<ABL, S::NP>()>(ex, lds, p.tw, src, dst);
+}
+// LDS bytes of a column-tile workgroup: the exchange buffer + the staged twiddle tables
+template <class T, class S, int F, bool SPLIT, int ABL> constexpr size_t k2_lds_bytes() {
+    return lds_bytes_twl<T, S, F, SPLIT, k2_pitch_mod(F), k2_twl<ABL, S::NP>()>() + ((ABL & 512) ? 4096 : 0);
 }
 
 // ---- large-N pass for lengths that are not powers of two ------------------------------------------------------------
@@ -262,7 +279,7 @@ template <class T, bool FIRST, int FUSE = 0> struct K2gSrc {
     }
 };
 
-template <class T, class S, int F, bool FIRST, int FUSE, bool SPLIT = false, class X>
+template <class T, class S, int F, bool FIRST, int FUSE, bool SPLIT = false, int TWL = 0, class X>
 MI_HD void k2g_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     static_assert(FUSE == 0 || (FUSE == 1) == FIRST, "chirp-in fuses into a first pass, the output stages into a last pass");
     constexpr int R = S::N;
@@ -318,7 +335,7 @@ MI_HD void k2g_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
             }
         }
     };
-    wg_fft<T, S, F, MAP_FF, FIRST ? MAP_EF : MAP_FF, SPLIT, false, k2_pitch_mod(F)>(ex, lds, p.tw, src, dst);
+    wg_fft<T, S, F, MAP_FF, FIRST ? MAP_EF : MAP_FF, SPLIT, false, k2_pitch_mod(F), 0, -1, false, (S::NP >= 2 ? TWL : 0)>(ex, lds, p.tw, src, dst);
 }
 
 // ---- Bluestein: any length n <= (M + 1) / 2 through two length-M workgroup transforms ---------------------

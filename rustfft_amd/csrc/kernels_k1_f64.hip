@@ -25,6 +25,13 @@ void register_k1_f64(std::vector<KernelEntry>& reg) {
     // 2^13, 2^14 in one kernel (split exchange): 10.0 / 10.1 TFLOP/s (5.05 / 4.7 TB/s) against 5.8 / 6.1 for two passes
     MI_K1(double, 64, 1, true, 8192, 512, 8, 8, 8, 16);  // 5.44 TB/s against 5.22 for 16 x 8 x 8 x 8
     MI_K1(double, 64, 1, true, 16384, 512, 16, 32, 32);
+    MI_K1ABL(31, 1024, double, 64, 4, false, 1024, 64, 16, 16, 4);
+    MI_K1ABL(31, 1024, double, 64, 2, false, 2048, 128, 16, 16, 8);
+    MI_K1ABL(31, 1024, double, 64, 1, false, 4096, 512, 8, 8, 8, 8);
+    MI_K1ABL(31, 1024, double, 64, 1, true, 8192, 512, 8, 8, 8, 16);
+    MI_K1ABL(31, 1024, double, 64, 1, true, 16384, 512, 16, 32, 32);
+    MI_K1ABL(30, 128, double, 64, 4, false, 1024, 64, 16, 16, 4);
+    MI_K1ABL(30, 128, double, 64, 8, false, 512, 32, 16, 8, 4);
     MI_K1V(3, double, 64, 1, true, 16384, 1024, 16, 16, 8, 8);
     MI_K1V(5, double, 64, 1, false, 4096, 256, 16, 16, 16);  // tuning: the schedules the two above replaced
     MI_K1V(5, double, 64, 1, true, 8192, 512, 16, 8, 8, 8);

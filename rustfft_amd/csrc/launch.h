@@ -100,17 +100,17 @@ template <class T, class S, int F, bool SPLIT, int ABL = 0> KernelEntry make_k1(
     e.f = F;
     fill_sched<S>(e);
     e.threads = F * S::TPF;
-    e.lds_bytes = lds_bytes<T, S, F, SPLIT>();
+    e.lds_bytes = k1_lds_bytes<T, S, F, SPLIT, ABL>();
     e.split = SPLIT;
     e.name = name;
     e.launch = [](const void* params, long long grid, void* stream) {
         void* args[] = {const_cast<void*>(params)};
         (void)hipLaunchKernel((const void*)k1_kernel<T, S, F, SPLIT, ABL>, dim3((unsigned)grid), dim3(F * S::TPF), args,
-                              lds_bytes<T, S, F, SPLIT>(), (hipStream_t)stream);
+                              k1_lds_bytes<T, S, F, SPLIT, ABL>(), (hipStream_t)stream);
     };
     e.prepare = []() -> int {
         return (int)hipFuncSetAttribute((const void*)k1_kernel<T, S, F, SPLIT, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds_bytes<T, S, F, SPLIT>());
+                                        (int)k1_lds_bytes<T, S, F, SPLIT, ABL>());
     };
     return e;
 }
@@ -122,17 +122,17 @@ template <class T, class S, int F, bool FIRST, bool SPLIT, int ABL = 0> KernelEn
     e.f = F;
     fill_sched<S>(e);
     e.threads = F * S::TPF;
-    e.lds_bytes = lds_bytes<T, S, F, SPLIT, k2_pitch_mod(F)>();
+    e.lds_bytes = k2_lds_bytes<T, S, F, SPLIT, ABL>();
     e.split = SPLIT;
     e.name = name;
     e.launch = [](const void* params, long long grid, void* stream) {
         void* args[] = {const_cast<void*>(params)};
         (void)hipLaunchKernel((const void*)k2_kernel<T, S, F, FIRST, SPLIT, ABL>, dim3((unsigned)grid), dim3(F * S::TPF), args,
-                              lds_bytes<T, S, F, SPLIT, k2_pitch_mod(F)>(), (hipStream_t)stream);
+                              k2_lds_bytes<T, S, F, SPLIT, ABL>(), (hipStream_t)stream);
     };
     e.prepare = []() -> int {
         return (int)hipFuncSetAttribute((const void*)k2_kernel<T, S, F, FIRST, SPLIT, ABL>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<T, S, F, SPLIT, k2_pitch_mod(F)>());
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2_lds_bytes<T, S, F, SPLIT, ABL>());
     };
     return e;
 }
@@ -236,13 +236,16 @@ template <class T, class S, bool FIRST, int FUSE, bool SPLIT, int THREADS> const
     if (sizeof(T) == 8) return (FUSE >= 2 && S::N >= 256) ? 1 : 4;
     return (!FIRST && FUSE == 0 && S::R[0] == 15 && (S::N == 300 || S::N == 375 || S::N == 450)) ? 4 : 1;
 }
-template <class T, class S, int F, bool FIRST, int FUSE, bool SPLIT>
+template <class T, class S, int F, bool FIRST, int FUSE, bool SPLIT, int TWL>
 __global__ __launch_bounds__(F* S::TPF, (k2g_min_waves<T, S, FIRST, FUSE, SPLIT, F * S::TPF>())) void k2g_kernel(K2Params<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevExec<T, regs_needed<S, SPLIT>()> ex;
-    k2g_body<T, S, F, FIRST, FUSE, SPLIT>(ex, p, (long long)blockIdx.x, smem);
+    k2g_body<T, S, F, FIRST, FUSE, SPLIT, TWL>(ex, p, (long long)blockIdx.x, smem);
 }
-template <class T, class S, int F, bool FIRST, int FUSE = 0, bool SPLIT = false> KernelEntry make_k2g(int prec, const char* name) {
+// TWL: sub-pass twiddle tables staged in LDS (engine.h); -1 = all of them
+template <class S> constexpr int k2g_twl(int twl) { return S::NP < 2 ? 0 : twl < 0 ? twl_all(S::NP) : twl; }
+template <class T, class S, int F, bool FIRST, int FUSE = 0, bool SPLIT = false, int TWL_ = 0> KernelEntry make_k2g(int prec, const char* name) {
+    constexpr int TWL = k2g_twl<S>(TWL_);
     KernelEntry e{};
     e.kind = FUSE == 1 ? KIND_K2G_FIRST_CHIRP : FUSE == 2 ? KIND_K2G_LAST_MUL : FUSE == 3 ? KIND_K2G_LAST_CHIRP : FIRST ? KIND_K2G_FIRST : KIND_K2G_LATER;
     e.prec = prec;
@@ -250,17 +253,17 @@ template <class T, class S, int F, bool FIRST, int FUSE = 0, bool SPLIT = false>
     e.f = F;
     fill_sched<S>(e);
     e.threads = F * S::TPF;
-    e.lds_bytes = lds_bytes<T, S, F, SPLIT, k2_pitch_mod(F)>();
+    e.lds_bytes = lds_bytes_twl<T, S, F, SPLIT, k2_pitch_mod(F), TWL>();
     e.split = SPLIT;
     e.name = name;
     e.launch = [](const void* params, long long grid, void* stream) {
         void* args[] = {const_cast<void*>(params)};
-        (void)hipLaunchKernel((const void*)k2g_kernel<T, S, F, FIRST, FUSE, SPLIT>, dim3((unsigned)grid), dim3(F * S::TPF), args,
-                              lds_bytes<T, S, F, SPLIT, k2_pitch_mod(F)>(), (hipStream_t)stream);
+        (void)hipLaunchKernel((const void*)k2g_kernel<T, S, F, FIRST, FUSE, SPLIT, TWL>, dim3((unsigned)grid), dim3(F * S::TPF), args,
+                              lds_bytes_twl<T, S, F, SPLIT, k2_pitch_mod(F), TWL>(), (hipStream_t)stream);
     };
     e.prepare = []() -> int {
-        return (int)hipFuncSetAttribute((const void*)k2g_kernel<T, S, F, FIRST, FUSE, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)lds_bytes<T, S, F, SPLIT, k2_pitch_mod(F)>());
+        return (int)hipFuncSetAttribute((const void*)k2g_kernel<T, S, F, FIRST, FUSE, SPLIT, TWL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds_bytes_twl<T, S, F, SPLIT, k2_pitch_mod(F), TWL>());
     };
     return e;
 }
@@ -375,11 +378,11 @@ template <class T, class S, int F, bool SPLIT, int ABL = 0> KernelEntry make_k1(
     e.f = F;
     fill_sched<S>(e);
     e.threads = F * S::TPF;
-    e.lds_bytes = lds_bytes<T, S, F, SPLIT>();
+    e.lds_bytes = k1_lds_bytes<T, S, F, SPLIT, ABL>();
     e.split = SPLIT;
     e.name = name;
     e.launch = [](const void* params, long long grid, void*) {
-        std::vector<char> lds(lds_bytes<T, S, F, SPLIT>() + 64, (char)0x5a);  // poisoned LDS
+        std::vector<char> lds(k1_lds_bytes<T, S, F, SPLIT, ABL>() + 64, (char)0x5a);  // poisoned LDS
         for (long long b = 0; b < grid; ++b) {
             HostExec<T, regs_needed<S, SPLIT>()> ex(F * S::TPF);
             k1_body<T, S, F, SPLIT, ABL>(ex, *(const K1Params<T>*)params, b, lds.data());
@@ -396,11 +399,11 @@ template <class T, class S, int F, bool FIRST, bool SPLIT, int ABL = 0> KernelEn
     e.f = F;
     fill_sched<S>(e);
     e.threads = F * S::TPF;
-    e.lds_bytes = lds_bytes<T, S, F, SPLIT, k2_pitch_mod(F)>();
+    e.lds_bytes = k2_lds_bytes<T, S, F, SPLIT, ABL>();
     e.split = SPLIT;
     e.name = name;
     e.launch = [](const void* params, long long grid, void*) {
-        std::vector<char> lds(lds_bytes<T, S, F, SPLIT, k2_pitch_mod(F)>() + 64, (char)0x5a);
+        std::vector<char> lds(k2_lds_bytes<T, S, F, SPLIT, ABL>() + 64, (char)0x5a);
         for (long long b = 0; b < grid; ++b) {
             HostExec<T, regs_needed<S, SPLIT>()> ex(F * S::TPF);
             k2_body<T, S, F, FIRST, SPLIT, ABL>(ex, *(const K2Params<T>*)params, b, lds.data());
@@ -476,7 +479,9 @@ template <class T, class S, int F, int MODE> KernelEntry make_rader(int prec, co
     e.prepare = []() -> int { return 0; };
     return e;
 }
-template <class T, class S, int F, bool FIRST, int FUSE = 0, bool SPLIT = false> KernelEntry make_k2g(int prec, const char* name) {
+template <class S> constexpr int k2g_twl(int twl) { return S::NP < 2 ? 0 : twl < 0 ? twl_all(S::NP) : twl; }
+template <class T, class S, int F, bool FIRST, int FUSE = 0, bool SPLIT = false, int TWL_ = 0> KernelEntry make_k2g(int prec, const char* name) {
+    constexpr int TWL = k2g_twl<S>(TWL_);
     KernelEntry e{};
     e.kind = FUSE == 1 ? KIND_K2G_FIRST_CHIRP : FUSE == 2 ? KIND_K2G_LAST_MUL : FUSE == 3 ? KIND_K2G_LAST_CHIRP : FIRST ? KIND_K2G_FIRST : KIND_K2G_LATER;
     e.prec = prec;
@@ -484,14 +489,14 @@ template <class T, class S, int F, bool FIRST, int FUSE = 0, bool SPLIT = false>
     e.f = F;
     fill_sched<S>(e);
     e.threads = F * S::TPF;
-    e.lds_bytes = lds_bytes<T, S, F, SPLIT, k2_pitch_mod(F)>();
+    e.lds_bytes = lds_bytes_twl<T, S, F, SPLIT, k2_pitch_mod(F), TWL>();
     e.split = SPLIT;
     e.name = name;
     e.launch = [](const void* params, long long grid, void*) {
-        std::vector<char> lds(lds_bytes<T, S, F, SPLIT, k2_pitch_mod(F)>() + 64, (char)0x5a);
+        std::vector<char> lds(lds_bytes_twl<T, S, F, SPLIT, k2_pitch_mod(F), TWL>() + 64, (char)0x5a);
         for (long long b = 0; b < grid; ++b) {
             HostExec<T, regs_needed<S, SPLIT>()> ex(F * S::TPF);
-            k2g_body<T, S, F, FIRST, FUSE, SPLIT>(ex, *(const K2Params<T>*)params, b, lds.data());
+            k2g_body<T, S, F, FIRST, FUSE, SPLIT, TWL>(ex, *(const K2Params<T>*)params, b, lds.data());
         }
     };
     e.prepare = []() -> int { return 0; };
@@ -577,9 +582,25 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
     reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, true, SPLIT>(PREC, "k2first<" #__VA_ARGS__ ">xF" #F)); \
     reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, false, SPLIT>(PREC, "k2later<" #__VA_ARGS__ ">xF" #F))
 
+// production instantiations with options (ABL: 64 pair-fused, 128 / 1024 / 2048 sub-pass twiddle tables staged in LDS: all /
+// sub-pass 1 / the last sub-pass); SUF is appended to the kernel name ("t", "t1", "tl")
+#define MI_K1X(T, PREC, F, SPLIT, ABL, SUF, ...) reg.push_back(make_k1<T, Sched<__VA_ARGS__>, F, SPLIT, ABL>(PREC, "k1<" #__VA_ARGS__ ">xF" #F SUF))
+#define MI_K2X_FIRST(T, PREC, F, SPLIT, ABL, SUF, ...) reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, true, SPLIT, ABL>(PREC, "k2first<" #__VA_ARGS__ ">xF" #F SUF))
+#define MI_K2X_LATER(T, PREC, F, SPLIT, ABL, SUF, ...) reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, false, SPLIT, ABL>(PREC, "k2later<" #__VA_ARGS__ ">xF" #F SUF))
+#define MI_K2X(T, PREC, F, SPLIT, ABL, SUF, ...)         \
+    MI_K2X_FIRST(T, PREC, F, SPLIT, ABL, SUF, __VA_ARGS__); \
+    MI_K2X_LATER(T, PREC, F, SPLIT, ABL, SUF, __VA_ARGS__)
+// general column tiles: MI355_K2G_TWL (a build-wide switch of the A/B builds) / MI_K2GT: every sub-pass table staged in LDS
+#if defined(MI355_K2G_TWL)
+#define MI_K2G(T, PREC, F, ...) MI_K2GT(T, PREC, F, __VA_ARGS__)
+#else
 #define MI_K2G(T, PREC, F, ...)                                                                        \
     reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, true>(PREC, "k2gfirst<" #__VA_ARGS__ ">xF" #F));  \
     reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, false>(PREC, "k2glater<" #__VA_ARGS__ ">xF" #F))
+#endif
+#define MI_K2GT(T, PREC, F, ...)                                                                                      \
+    reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, true, 0, false, -1>(PREC, "k2gfirst<" #__VA_ARGS__ ">xF" #F "t"));  \
+    reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, false, 0, false, -1>(PREC, "k2glater<" #__VA_ARGS__ ">xF" #F "t"))
 // tall general tiles (split exchange, 32 values per thread)
 #define MI_K2GS(T, PREC, F, ...)                                                                                      \
     reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, true, 0, true>(PREC, "k2gfirst<" #__VA_ARGS__ ">xF" #F "s"));  \
