@@ -156,6 +156,59 @@ def side_config(args, rank, local_rank, world, dist, log):
         dist.destroy_process_group()
 
 
+def side_line(torch, np, log, steps=3):
+    """BASELINE configs 3, 4 and the one-GPU shard of config 5 in the SAME JSON line (key "side"), so that the driver's record
+    carries them next to config 2: a few forward steps each through the immutable-input entry point, per-kernel HIP-event
+    durations, the dominant kernel's fraction of 8 TB/s, and a Parseval check of the last output over the WHOLE batch.
+    `value`, `config` and `roofline` of the line stay config 2's."""
+    import rustfft_amd
+
+    def energy(t, chunk=1 << 26):  # sum |t|^2 in f64, chunked: no batch-sized temporaries
+        v = torch.view_as_real(t).reshape(-1)
+        acc = 0.0
+        for i in range(0, v.numel(), chunk):
+            acc += float((v[i:i + chunk].double() ** 2).sum().item())
+        return acc
+
+    res = {}
+    for key, n, batch, dt, tdt, esz, name in (("c3", 1200, 65536, np.complex128, torch.complex128, 16, "f64"),
+                                             ("c4", 1009, 1 << 20, np.complex64, torch.complex64, 8, "f32"),
+                                             ("c5_shard", 1 << 22, 1024, np.complex64, torch.complex64, 8, "f32")):
+        try:
+            fft = rustfft_amd.FftPlanner(dt).plan_fft_forward(n)
+            g = torch.Generator(device="cuda")
+            g.manual_seed(0x52555354 + n)
+            x = torch.empty(batch * n, dtype=tdt, device="cuda")
+            torch.view_as_real(x).uniform_(-1.0, 1.0, generator=g)
+            y = torch.empty_like(x)
+            fft.process_immutable_with_scratch(x, y)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(steps):
+                fft.process_immutable_with_scratch(x, y)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / steps
+            ex, ey = energy(x), energy(y)
+            kms = fft.profile_kernels(y, reps=steps)
+            alg = batch * 2 * n * esz
+            per_kernel = [{"kernel": nm, "ms": k, "GBps": alg / (k * 1e-3) / 1e9} for nm, k in zip(fft.kernel_names(), kms) if k > 0]
+            dom = max(per_kernel, key=lambda r: r["ms"])
+            res[key] = {"workload": f"N={n} Complex<{name}>, batch={batch}, forward, immutable input, HBM-resident", "plan": fft.describe(), "steps": steps,
+                        "ms_per_step": ms, "GFLOPs": batch * 5.0 * n * math.log2(n) / (ms * 1e-3) / 1e9, "dominant_kernel": dom["kernel"],
+                        "dominant_GBps": dom["GBps"], "frac_of_8TBps": dom["GBps"] / HBM_PEAK_GBS, "kernels": per_kernel,
+                        "check": {"parseval_rel_err": abs(ey / n - ex) / ex, "what": "sum|X|^2 / N vs sum|x|^2 over the whole batch, x re/im ~ U[-1,1)"}}
+            if res[key]["check"]["parseval_rel_err"] > (1e-4 if esz == 8 else 1e-10):
+                res[key]["check"]["FAILED"] = True
+            del x, y, fft
+            torch.cuda.empty_cache()
+        except Exception as e:  # side numbers never fail the line
+            res[key] = {"error": str(e)}
+            log(f"side config {key} failed: {e}")
+    return res
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without torchrun: start one process per GPU (rank i on GPU i) with the torchrun
     environment contract (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) and relay rank 0's JSON line."""
@@ -279,6 +332,7 @@ def main():
                     help="BASELINE.json config: c2 (default, the metric's config) N=2^20 f32 x1024 fwd+inv; c3 N=1200 f64 x65536; "
                          "c4 N=1009 f32 x2^20; c5 N=2^22 f32 x1024 per GPU (8192 over 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side", action="store_true", help="skip the side configs (BASELINE configs 3, 4 and config 5's one-GPU shard) in the JSON line")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for the one-GPU control-flow smoke test)")
     ap.add_argument("--one-device", action="store_true", help="smoke test of the N > 1 control flow on a one-GPU box: every rank uses cuda:0")
@@ -472,6 +526,11 @@ def main():
                                                              "algorithmic_bytes": alg_bytes, "unit": "bytes per launch"}
             except Exception as e:
                 log(f"pmc traffic unavailable: {e}")
+        if world == 1 and not args.no_side:
+            del data
+            data = None
+            torch.cuda.empty_cache()
+            out["side"] = side_line(torch, np, log)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(n, log)

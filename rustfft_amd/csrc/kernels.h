@@ -226,6 +226,11 @@ template <class T, class S, int F, bool SPLIT, int ABL> constexpr size_t k2_lds_
 // FUSE (multi-kernel Bluestein, bluesteins_algorithm.rs:100-136): 1 = the FIRST pass reads the caller's rows (pitch n),
 // multiplies by the chirp and zero-pads on the fly; 2 = the last pass stores conj(X * bf); 3 = the last pass stores
 // conj(X) * chirp, truncated to n, into the caller's rows.  0 = plain pass.
+// FUSE (multi-kernel Rader for primes p beyond one workgroup, raders_algorithm.rs:235-283, inner length N = p - 1): 4 = the FIRST
+// pass of the first inner transform gathers x[g^(j+1) mod p] from the caller's rows (pitch p); 5 = its last pass stores
+// conj(S[j] d[j]), folds conj(x[0]) into element 0 and writes X[0] = x[0] + S[0] to the caller's output row; 6 = the last pass
+// of the second inner transform scatters conj(S[j]) to X[g^-(j+1) mod p] of the caller's rows.  The permutations are random
+// within a row, i.e. within a 4(p - 1)-byte .. 8(p - 1)-byte span that the L2 holds: HBM still sees each row once.
 template <class T, bool FIRST, int FUSE = 0> struct K2gSrc {
     const cx<T>* in;
     unsigned M, S, b0;
@@ -235,6 +240,7 @@ template <class T, bool FIRST, int FUSE = 0> struct K2gSrc {
     int hshift, lmask;
     const cx<T>* MI_RESTRICT tab;
     unsigned n_valid;
+    const int* MI_RESTRICT perm;
     MI_HD cx<T> lut(unsigned e) const { return tlo[e & (unsigned)lmask] * thi[e >> hshift]; }
     template <int R, int LOG, int K, int J0> MI_HD static void apply_tw(cx<T>* v, cx<T> w, const cx<T>* sp) {
         v[K] = v[K] * w;
@@ -256,6 +262,10 @@ template <class T, bool FIRST, int FUSE = 0> struct K2gSrc {
                     x.im *= sgn_in;
                     x = x * tab[idx];
                 }
+                v[k] = x;
+            } else if constexpr (FUSE == 4) {
+                cx<T> x = in[(unsigned)perm[idx]];
+                x.im *= sgn_in;
                 v[k] = x;
             } else {
                 cx<T> x = in[idx];
@@ -281,7 +291,7 @@ template <class T, bool FIRST, int FUSE = 0> struct K2gSrc {
 
 template <class T, class S, int F, bool FIRST, int FUSE, bool SPLIT = false, int TWL = 0, class X>
 MI_HD void k2g_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
-    static_assert(FUSE == 0 || (FUSE == 1) == FIRST, "chirp-in fuses into a first pass, the output stages into a last pass");
+    static_assert(FUSE == 0 || (FUSE == 1 || FUSE == 4) == FIRST, "chirp-in / gather fuse into a first pass, the output stages into a last pass");
     constexpr int R = S::N;
     // XCD-aware tile order as in k2_body, over the GLOBAL workgroup index (tile counts are not multiples of 64 here): every
     // complete aligned group of 64 workgroups is permuted so that XCD x takes runs of 2^XP adjacent tiles (XCD id at address
@@ -305,13 +315,17 @@ MI_HD void k2g_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
         g = block / p.tiles_per_fft;
         b0 = (unsigned)(block % p.tiles_per_fft) * (unsigned)F;
     }
-    const cx<T>* in = p.in + g * (FUSE == 1 ? p.n_io : p.n);
-    cx<T>* out = p.out + g * (FUSE == 3 ? p.n_io : p.n);
+    const cx<T>* in = p.in + g * ((FUSE == 1 || FUSE == 4) ? p.n_io : p.n);
+    cx<T>* out = p.out + g * ((FUSE == 3 || FUSE == 6) ? p.n_io : p.n);
+    const int* MI_RESTRICT perm = p.perm;
+    const cx<T>* xin = FUSE == 5 ? p.xin + g * p.n_io : nullptr;
+    cx<T>* xout = FUSE == 5 ? p.xout + g * p.n_io : nullptr;
+    const T sgn_x = p.sgn_x;
     const unsigned M = (unsigned)p.m, Sg = (unsigned)p.s;
     const T sgn_out = p.sgn_out;
     const cx<T>* MI_RESTRICT tab = p.tab;
     const unsigned n_valid = p.n_valid;
-    K2gSrc<T, FIRST, FUSE> src{in, M, Sg, b0, p.sgn_in, p.tlo, p.thi, p.hshift, p.lmask, tab, n_valid};
+    K2gSrc<T, FIRST, FUSE> src{in, M, Sg, b0, p.sgn_in, p.tlo, p.thi, p.hshift, p.lmask, tab, n_valid, perm};
     auto dst = [=](int f, int k, cx<T> x) {
         const unsigned B = b0 + (unsigned)f;
         if (B < M) {
@@ -328,6 +342,21 @@ MI_HD void k2g_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
                         y.im *= sgn_out;
                         out[e] = y;
                     }
+                } else if constexpr (FUSE == 5) {
+                    cx<T> t = cconj(x * tab[e]);
+                    if (e == 0) {  // raders_algorithm.rs:257-266: X[0] = x[0] + S[0]; S[0] d[0] picks up conj(x[0])
+                        cx<T> x0 = xin[0];
+                        x0.im *= sgn_x;
+                        t = t + cconj(x0);
+                        cx<T> X0 = x0 + x;
+                        X0.im *= sgn_x;
+                        xout[0] = X0;
+                    }
+                    out[e] = t;
+                } else if constexpr (FUSE == 6) {
+                    cx<T> y = cconj(x);
+                    y.im *= sgn_out;
+                    out[(unsigned)perm[e]] = y;
                 } else {
                     x.im *= sgn_out;
                     out[e] = x;

@@ -36,6 +36,13 @@ template <class T> struct K2Params {
     const cx<T>* tab;   // FUSE 1, 3: chirp[n_valid]; FUSE 2: spectrum multiplier bf[N]
     long long n_io;     // FUSE 1: row pitch of `in`; FUSE 3: row pitch of `out` (the caller's length n, not N)
     unsigned n_valid;   // FUSE 1: elements >= n_valid of a row are zero padding; FUSE 3: only elements < n_valid are stored
+    // fused multi-kernel Rader (k2g_body FUSE 4, 5, 6; raders_algorithm.rs:235-283 with inner length N = p - 1, caller rows of pitch
+    // n_io = p): FUSE 4 loads x[perm[idx]] (perm = g^(j+1) mod p); FUSE 5 stores conj(X * tab) (tab = d), adds conj(x[0]) to
+    // element 0 and writes X[0] = x[0] + S[0] into the caller's output row; FUSE 6 stores conj(X) at perm[e] (perm = g^-(j+1) mod p)
+    const int* perm;
+    const cx<T>* xin;  // the caller's input rows (x[0] of every row)
+    cx<T>* xout;       // the caller's output rows (X[0] of every row)
+    T sgn_x;           // -1 for the inverse plan (conj on the way in and out), +1 otherwise: every pass of the sequence sees it
 };
 
 // Bluestein (chirp-z) in one workgroup, src/algorithm/bluesteins_algorithm.rs:100-136:

@@ -247,7 +247,7 @@ template <class S> constexpr int k2g_twl(int twl) { return S::NP < 2 ? 0 : twl <
 template <class T, class S, int F, bool FIRST, int FUSE = 0, bool SPLIT = false, int TWL_ = 0> KernelEntry make_k2g(int prec, const char* name) {
     constexpr int TWL = k2g_twl<S>(TWL_);
     KernelEntry e{};
-    e.kind = FUSE == 1 ? KIND_K2G_FIRST_CHIRP : FUSE == 2 ? KIND_K2G_LAST_MUL : FUSE == 3 ? KIND_K2G_LAST_CHIRP : FIRST ? KIND_K2G_FIRST : KIND_K2G_LATER;
+    e.kind = FUSE == 1 ? KIND_K2G_FIRST_CHIRP : FUSE == 2 ? KIND_K2G_LAST_MUL : FUSE == 3 ? KIND_K2G_LAST_CHIRP : FUSE == 4 ? KIND_K2G_FIRST_GATHER : FUSE == 5 ? KIND_K2G_LAST_RMUL : FUSE == 6 ? KIND_K2G_LAST_SCATTER : FIRST ? KIND_K2G_FIRST : KIND_K2G_LATER;
     e.prec = prec;
     e.n = S::N;
     e.f = F;
@@ -483,7 +483,7 @@ template <class S> constexpr int k2g_twl(int twl) { return S::NP < 2 ? 0 : twl <
 template <class T, class S, int F, bool FIRST, int FUSE = 0, bool SPLIT = false, int TWL_ = 0> KernelEntry make_k2g(int prec, const char* name) {
     constexpr int TWL = k2g_twl<S>(TWL_);
     KernelEntry e{};
-    e.kind = FUSE == 1 ? KIND_K2G_FIRST_CHIRP : FUSE == 2 ? KIND_K2G_LAST_MUL : FUSE == 3 ? KIND_K2G_LAST_CHIRP : FIRST ? KIND_K2G_FIRST : KIND_K2G_LATER;
+    e.kind = FUSE == 1 ? KIND_K2G_FIRST_CHIRP : FUSE == 2 ? KIND_K2G_LAST_MUL : FUSE == 3 ? KIND_K2G_LAST_CHIRP : FUSE == 4 ? KIND_K2G_FIRST_GATHER : FUSE == 5 ? KIND_K2G_LAST_RMUL : FUSE == 6 ? KIND_K2G_LAST_SCATTER : FIRST ? KIND_K2G_FIRST : KIND_K2G_LATER;
     e.prec = prec;
     e.n = S::N;
     e.f = F;
@@ -614,6 +614,11 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
     reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, true, 1>(PREC, "k2gfirst_chirp<" #__VA_ARGS__ ">xF" #F)); \
     reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, false, 2>(PREC, "k2glast_mul<" #__VA_ARGS__ ">xF" #F));   \
     reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, false, 3>(PREC, "k2glast_chirp<" #__VA_ARGS__ ">xF" #F))
+// the three fused passes of the multi-kernel Rader for one tile height
+#define MI_K2GR(T, PREC, F, ...)                                                                                \
+    reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, true, 4>(PREC, "k2gfirst_gather<" #__VA_ARGS__ ">xF" #F));  \
+    reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, false, 5>(PREC, "k2glast_rmul<" #__VA_ARGS__ ">xF" #F));    \
+    reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, false, 6>(PREC, "k2glast_scatter<" #__VA_ARGS__ ">xF" #F))
 // Bluestein bodies take the linear exchange layout (SchedL): 164 -> 124 VGPRs for the power-of-two inner lengths
 #define MI_BS(T, PREC, F, ...) reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F))
 // one-kernel Bluestein through the split exchange (padded lengths above 8192: one workgroup per row)

@@ -60,6 +60,14 @@ void ensure_registry() {
         register_k2g_f64_5(r);
         register_k2g_f64_6(r);
         register_k2g_f64_7(r);
+        register_k2gr_f32_0(r);
+        register_k2gr_f32_1(r);
+        register_k2gr_f32_2(r);
+        register_k2gr_f32_3(r);
+        register_k2gr_f64_0(r);
+        register_k2gr_f64_1(r);
+        register_k2gr_f64_2(r);
+        register_k2gr_f64_3(r);
         register_smooth_f32_0(r);
         register_smooth_f32_1(r);
         register_smooth_f32_2(r);
@@ -788,6 +796,34 @@ template <class T> static int build_plan_t(Plan& plan) {
             return MI355FFT_OK;
         }
     }
+    // primes beyond one workgroup whose p - 1 factors into general tile heights: multi-kernel Rader (raders_algorithm.rs:126-283; the
+    // reference's planner takes Rader for exactly these primes, src/plan.rs:636-665).  Two inner transforms of length p - 1, each two
+    // to four column-tile passes; the g^j gather, the spectrum multiply with the x[0] / X[0] step and the g^-j scatter ride on the
+    // first load / last stores (k2g_body FUSE 4, 5, 6).  Traffic: 4 P (p - 1) elements against 4 P M, M >= 2p - 1, for the fused
+    // Bluestein that served these primes before.  AUTO takes it above 8192 (below, the one-kernel Bluestein through the split
+    // exchange moves each row once: measured choice, profiles/r3/rader_large_ab.jsonl); a host planner's MI355FFT_ALGO_RADER
+    // gets it for every such prime.
+    if (rader_ok && n > 4096 && n < ((size_t)1 << 31) && is_prime_sz(n) && (algo == MI355FFT_ALGO_RADER || n > 8192 || env_int("MI355FFT_RADER_LARGE") == 1) &&
+        env_int("MI355FFT_RADER_LARGE") != 2) {
+        std::vector<size_t> radices;
+        if (choose_general_radices(plan.prec, n - 1, radices) && find_kernel(KIND_K2G_FIRST_GATHER, plan.prec, radices.front()) &&
+            find_kernel(KIND_K2G_LAST_RMUL, plan.prec, radices.back()) && find_kernel(KIND_K2G_LAST_SCATTER, plan.prec, radices.back())) {
+            PassDesc tabs{};
+            if ((rc = rader_tables<T>(plan, tabs, false))) return rc;
+            const size_t P = radices.size();
+            std::vector<int> k1(P, KIND_K2G_LATER), k2(P, KIND_K2G_LATER);
+            k1[0] = KIND_K2G_FIRST_GATHER;
+            k1[P - 1] = KIND_K2G_LAST_RMUL;
+            k2[0] = KIND_K2G_FIRST;
+            k2[P - 1] = KIND_K2G_LAST_SCATTER;
+            if ((rc = append_general_passes<T>(plan, n - 1, radices, k1, nullptr, tabs.d_aux1))) return rc;
+            plan.passes[0].d_perm_in = tabs.d_perm_in;
+            if ((rc = append_general_passes<T>(plan, n - 1, radices, k2, nullptr, nullptr))) return rc;
+            plan.passes.back().d_perm_in = tabs.d_perm_out;
+            plan.kind = PLAN_RADER_FUSED;
+            return MI355FFT_OK;
+        }
+    }
     // 13-smooth lengths that fit one workgroup: the run-time scheduled mixed-radix kernel (the RadixN analogue)
     if (direct_ok && env_int("MI355FFT_NO_DYN") == 0) {
         DynSched ds;
@@ -929,8 +965,8 @@ std::string Plan::describe() const {
         s << "bluestein_large(M=" << inner->len << ": " << inner->describe() << ")";
         return s.str();
     }
-    if (kind == PLAN_BLUESTEIN_FUSED) {
-        s << "bluestein_large(M=" << passes[0].row_n << " fused: ";
+    if (kind == PLAN_BLUESTEIN_FUSED || kind == PLAN_RADER_FUSED) {
+        s << (kind == PLAN_RADER_FUSED ? "rader_large(p-1=" : "bluestein_large(M=") << passes[0].row_n << " fused: ";
         for (size_t i = 0; i < passes.size(); ++i) s << (i == 0 ? "" : (i == passes.size() / 2 ? " | " : " -> ")) << passes[i].k->name;
         s << ")";
         return s.str();
@@ -1008,7 +1044,8 @@ size_t Plan::trim_workspaces() {
 // truncated launch would transform a subset of the rows silently: checked before every launch.
 static const long long kMaxGrid = 0x7fffffffLL;
 template <class T>
-static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, size_t batch, void* stream, Tracer* tr) {
+static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, size_t batch, void* stream, Tracer* tr, const void* xin = nullptr,
+                       void* xout = nullptr) {
     const PassDesc& pd = plan.passes[pi];
     const KernelEntry& k = *pd.k;
     const bool inverse = plan.direction == MI355FFT_INVERSE;
@@ -1090,7 +1127,11 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         p.m = pd.m;
         p.s = pd.s;
         p.batch = (long long)batch;
-        p.tab = (const cx<T>*)pd.d_aux1;  // fused Bluestein passes only
+        p.tab = (const cx<T>*)pd.d_aux1;  // fused Bluestein / Rader passes only
+        p.perm = (const int*)pd.d_perm_in;  // fused Rader: g^(j+1) on the gather pass, g^-(j+1) on the scatter pass
+        p.xin = (const cx<T>*)xin;
+        p.xout = (cx<T>*)xout;
+        p.sgn_x = inverse ? (T)-1 : (T)1;
         p.n_io = (long long)plan.len;
         p.n_valid = (unsigned)plan.len;
         const bool general = (k.kind == KIND_K2G_FIRST || k.kind == KIND_K2G_LATER || k.kind >= KIND_K2G_FIRST_CHIRP);
@@ -1153,7 +1194,7 @@ template <class T> static int execute_t(Plan& plan, const void* in, void* out, s
         }
         return MI355FFT_OK;
     }
-    if (plan.kind == PLAN_BLUESTEIN_FUSED) {
+    if (plan.kind == PLAN_BLUESTEIN_FUSED || plan.kind == PLAN_RADER_FUSED) {
         // two transforms of length M, P passes each: caller rows -> A [-> B ...] -> (in place) | -> other [...] -> caller rows
         const size_t M = (size_t)plan.passes[0].row_n, P = plan.passes.size() / 2;
         size_t chunk = std::max<size_t>(1, ((size_t)1 << 31) / (M * esz));  // <= 2 x 2 GiB of padded rows at a time
@@ -1170,7 +1211,7 @@ template <class T> static int execute_t(Plan& plan, const void* in, void* out, s
             for (size_t pi = 0; pi < 2 * P; ++pi) {
                 const bool last1 = (pi == P - 1), last2 = (pi == 2 * P - 1);
                 char* dst = last2 ? (char*)out + c0 * n * esz : last1 ? (char*)src : bufs[1 - cur];
-                int rc = launch_pass<T>(plan, pi, src, dst, rows, stream, c0 == 0 ? tr : nullptr);
+                int rc = launch_pass<T>(plan, pi, src, dst, rows, stream, c0 == 0 ? tr : nullptr, (const char*)in + c0 * n * esz, (char*)out + c0 * n * esz);
                 if (rc) return rc;
                 if (!last1 && !last2) cur = 1 - cur;
                 src = dst;

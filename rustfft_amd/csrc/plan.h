@@ -29,7 +29,7 @@ struct DeviceGuard {
     DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 
-enum PlanKind { PLAN_TRIVIAL = 0, PLAN_SINGLE = 1, PLAN_MACRO = 2, PLAN_BLUESTEIN = 3, PLAN_RADER = 4, PLAN_BLUESTEIN_LARGE = 5, PLAN_BLUESTEIN_FUSED = 6, PLAN_BLUESTEIN_2K = 7 };
+enum PlanKind { PLAN_TRIVIAL = 0, PLAN_SINGLE = 1, PLAN_MACRO = 2, PLAN_BLUESTEIN = 3, PLAN_RADER = 4, PLAN_BLUESTEIN_LARGE = 5, PLAN_BLUESTEIN_FUSED = 6, PLAN_BLUESTEIN_2K = 7, PLAN_RADER_FUSED = 8 };
 
 struct PassDesc {
     const KernelEntry* k;

@@ -11,7 +11,11 @@ enum KernelKind { KIND_K1 = 1, KIND_K2_FIRST = 2, KIND_K2_LATER = 3, KIND_RADER 
                   // fused multi-kernel Bluestein passes (k2g_body FUSE = 1, 2, 3)
                   KIND_K2G_FIRST_CHIRP = 11, KIND_K2G_LAST_MUL = 12, KIND_K2G_LAST_CHIRP = 13,
                   // two-kernel Bluestein over one-workgroup transforms (k1bs_body STAGE 1 / 2)
-                  KIND_BS2_FIRST = 14, KIND_BS2_SECOND = 15 };
+                  KIND_BS2_FIRST = 14, KIND_BS2_SECOND = 15,
+                  // multi-kernel Rader for primes beyond one workgroup (k2g_body FUSE = 4, 5, 6): the g^j gather rides on the first
+                  // load of the first inner transform, the spectrum multiply + x[0] / X[0] step on its last store, the g^-j
+                  // scatter on the last store of the second one
+                  KIND_K2G_FIRST_GATHER = 16, KIND_K2G_LAST_RMUL = 17, KIND_K2G_LAST_SCATTER = 18 };
 
 struct KernelEntry {
     int kind;
@@ -59,6 +63,14 @@ void register_k2g_f64_4(std::vector<KernelEntry>&);
 void register_k2g_f64_5(std::vector<KernelEntry>&);
 void register_k2g_f64_6(std::vector<KernelEntry>&);
 void register_k2g_f64_7(std::vector<KernelEntry>&);
+void register_k2gr_f32_0(std::vector<KernelEntry>&);  // generated: the Rader-fused forms of the same tiles
+void register_k2gr_f32_1(std::vector<KernelEntry>&);
+void register_k2gr_f32_2(std::vector<KernelEntry>&);
+void register_k2gr_f32_3(std::vector<KernelEntry>&);
+void register_k2gr_f64_0(std::vector<KernelEntry>&);
+void register_k2gr_f64_1(std::vector<KernelEntry>&);
+void register_k2gr_f64_2(std::vector<KernelEntry>&);
+void register_k2gr_f64_3(std::vector<KernelEntry>&);
 // generated: compiled schedules for the 13-smooth lengths in (16, 4096] (tools/gen_smooth_kernels.py)
 void register_smooth_f32_0(std::vector<KernelEntry>&);
 void register_smooth_f32_1(std::vector<KernelEntry>&);

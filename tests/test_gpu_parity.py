@@ -692,6 +692,9 @@ def test_large_primes_vs_oracle(planners, oracle, dtype):
     for p in (12289, 40961, 65537, 112501):
         for d in (0, 1):
             fft = planner.plan_fft(p, d)
+            # round 3: multi-kernel Rader (gather / spectrum multiply / scatter fused into the column-tile passes of the two
+            # inner transforms of length p - 1) instead of the fused Bluestein over M >= 2p - 1
+            assert fft.describe().startswith("rader_large(p-1=%d fused: k2gfirst_gather<" % (p - 1)) and "k2glast_scatter<" in fft.describe(), fft.describe()
             check_fft_algorithm(fft, p, d, reference=oracle.plan(dtype, p, d), n=2)
             x = zero_mean_signal(p * 3, dtype, seed=p)
             y = x.copy()

@@ -1,0 +1,83 @@
+"""The Rust binding a maintainer would add lives in INTEGRATION.md as source (no rustc / cargo in this image or on the GPU
+box, so it cannot be compiled here): this test keeps it honest against include/mi355fft.h -- every `extern "C"` function the
+document declares must exist in the header with the same arity, the same pointer-ness / constness and the same scalar
+types; every mi355fft_* function the Rust snippets CALL must be declared in one of the extern blocks; and the #[repr(C)]
+Mi355PlanOptions must list the header's mi355fft_plan_options fields in the same order with matching types."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+C_TO_RUST = {
+    "int": "c_int", "size_t": "usize", "double": "f64", "void*": "*mut c_void", "const void*": "*const c_void",
+    "mi355fft_plan**": "*mut *mut Mi355Plan", "mi355fft_plan*": "*mut Mi355Plan", "const mi355fft_plan*": "*const Mi355Plan",
+    "const mi355fft_plan_options*": "*const Mi355PlanOptions", "const char*": "*const std::ffi::c_char", "char*": "*mut std::ffi::c_char",
+    "double*": "*mut f64", "size_t*": "*mut usize",
+    "mi355fft_twiddle_fn": "Option<extern \"C\" fn(*mut c_void, usize, usize, *mut f64, *mut f64)>",
+}
+
+
+def norm_c(t):
+    t = re.sub(r"\s+", " ", t.strip())
+    t = re.sub(r"\s*\*\s*", "*", t)
+    return t
+
+
+def c_prototypes(text):
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"^([A-Za-z_][\w\s\*]*?)\b(mi355fft_\w+)\s*\(([^;{}]*)\)\s*;", text, flags=re.M):
+        ret, name, args = norm_c(m.group(1)), m.group(2), m.group(3).strip()
+        params = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = norm_c(a)
+                mm = re.match(r"^(.*?[\*\s])(\w+)$", a)  # strip the parameter name
+                params.append(norm_c(mm.group(1)) if mm else a)
+        protos[name] = (ret, params)
+    return protos
+
+
+def rust_externs(text):
+    fns = {}
+    for block in re.findall(r'extern "C" \{(.*?)\n\}', text, flags=re.S):
+        for m in re.finditer(r"fn (mi355fft_\w+)\s*\((.*?)\)\s*(?:->\s*([^;]+))?;", block, flags=re.S):
+            args = [re.sub(r"\s+", " ", a.split(":", 1)[1].strip()) for a in re.split(r",(?![^<(]*[>)])", m.group(2)) if a.strip()]
+            fns[m.group(1)] = ((m.group(3) or "()").strip(), args)
+    return fns
+
+
+def test_extern_block_matches_the_header():
+    header = open(os.path.join(ROOT, "include", "mi355fft.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    protos, externs = c_prototypes(header), rust_externs(doc)
+    assert len(externs) >= 11, sorted(externs)
+    for name, (rret, rargs) in externs.items():
+        assert name in protos, f"INTEGRATION.md declares {name}, which include/mi355fft.h does not"
+        cret, cargs = protos[name]
+        assert C_TO_RUST[cret] == rret, (name, cret, rret)
+        assert len(cargs) == len(rargs), (name, cargs, rargs)
+        for ca, ra in zip(cargs, rargs):
+            assert C_TO_RUST[ca] == ra, (name, ca, ra)
+    # every entry point the Rust snippets call is declared
+    rust = "\n".join(re.findall(r"```rust(.*?)```", doc, flags=re.S))
+    for used in set(re.findall(r"\b(mi355fft_\w+)\s*\(", rust)):
+        assert used in externs, f"the Rust snippets call {used} without declaring it in an extern block"
+
+
+def test_plan_options_struct_matches_the_header():
+    header = open(os.path.join(ROOT, "include", "mi355fft.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    cbody = re.search(r"typedef struct mi355fft_plan_options \{(.*?)\} mi355fft_plan_options;", header, flags=re.S).group(1)
+    cfields = []
+    for line in cbody.split(";"):
+        line = norm_c(line)
+        if line:
+            mm = re.match(r"^(.*?[\*\s])(\w+)$", line)
+            cfields.append((mm.group(2), norm_c(mm.group(1))))
+    rbody = re.search(r"#\[repr\(C\)\]\s*struct Mi355PlanOptions \{(.*?)\n\}", doc, flags=re.S).group(1)
+    rbody = re.sub(r"//.*", "", rbody)
+    rfields = [(a.split(":", 1)[0].strip(), re.sub(r"\s+", " ", a.split(":", 1)[1].strip())) for a in re.split(r",(?![^<(]*[>)])", rbody) if a.strip()]
+    assert [f for f, _ in cfields] == [f for f, _ in rfields], (cfields, rfields)
+    for (cn, ct), (rn, rt) in zip(cfields, rfields):
+        assert C_TO_RUST[ct] == rt, (cn, ct, rt)

@@ -235,6 +235,40 @@ def test_lengths_beyond_one_workgroup(emu_planner, oracle, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_large_prime_rader(emu_planner, oracle, dtype):
+    """Primes beyond one workgroup whose p - 1 factors into general tile heights (the reference plans RadersAlgorithm for them,
+    src/plan.rs:636-665): the multi-kernel Rader -- g^j gather on the first load of the first inner transform, spectrum multiply
+    + x[0] / X[0] step on its last store, g^-j scatter on the last store of the second (k2g_body FUSE 4 / 5 / 6).  4481 lies below
+    AUTO's threshold (one-kernel Bluestein there) and is asked for as a host planner would; 65537 has a power-of-two inner length;
+    also the host planner's own inner_fft_data (raders_algorithm.rs:87-113) and a ragged batch."""
+    import rustfft_amd
+
+    planner = emu_planner(dtype)
+    for p, algo in ((4481, rustfft_amd.ALGO_RADER), (12289, rustfft_amd.ALGO_AUTO), (40961, rustfft_amd.ALGO_AUTO), (65537, rustfft_amd.ALGO_RADER)):
+        for d in (0, 1):
+            fft = planner.plan_fft_with(p, d, algorithm=algo)
+            assert fft.describe().startswith("rader_large(p-1=%d fused: k2gfirst_gather<" % (p - 1)), fft.describe()
+            assert "k2glast_rmul<" in fft.describe() and "k2glast_scatter<" in fft.describe(), fft.describe()
+            check_fft_algorithm(fft, p, d, reference=oracle.plan(dtype, p, d), n=2 if p < 20000 else 1)
+    assert "bluestein" in planner.plan_fft(4481, 0).describe()  # AUTO below the threshold
+    p = 12289
+    x = zero_mean_signal(p * 3, dtype, seed=5)
+    for d in (0, 1):
+        want = numpy_fft(x, p, d == 1)
+        g = oracle.primitive_root(p)
+        ginv, t = pow(g, p - 2, p), 1
+        data = np.zeros(p - 1, dtype=dtype)
+        for j in range(p - 1):
+            data[j] = oracle.compute_twiddle(dtype, t, p, d) / (p - 1)
+            t = t * ginv % p
+        oracle.plan(dtype, p - 1, d).process(data)
+        fft = planner.plan_fft_with(p, d, algorithm=rustfft_amd.ALGO_RADER, rader_inner_fft_data=data)
+        y = x.copy()
+        fft.process(y)
+        assert rel_l2(y, want) < (2e-6 if dtype == np.complex64 else 1e-13)
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_general_column_tile_passes(emu_planner, oracle, dtype):
     """7-smooth lengths above one workgroup (kernels.h k2g_body): 2, 3 and 4 passes, tile heights that do not divide
     the strides (per-column b mod s), ragged last tiles (M not a multiple of F), pure powers of 3 and 5.  The

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--bytes", type=float, default=1.0)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--rader", action="store_true", help="third arm: the plan a host planner gets with MI355FFT_ALGO_RADER (primes only)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -28,8 +29,13 @@ def main():
         batch = max(1, int(args.bytes * 2**30) // (n * esz))
         x = torch.empty(batch * n, dtype=tdt, device="cuda")
         out = {"n": n, "dtype": args.dtype, "batch": batch}
-        for name, algo in (("auto", rustfft_amd.ALGO_AUTO), ("bluestein", rustfft_amd.ALGO_BLUESTEIN)):
-            fft = planner.plan_fft_with(n, 0, algorithm=algo)
+        arms = [("auto", rustfft_amd.ALGO_AUTO), ("bluestein", rustfft_amd.ALGO_BLUESTEIN)] + ([("rader", rustfft_amd.ALGO_RADER)] if args.rader else [])
+        for name, algo in arms:
+            try:
+                fft = planner.plan_fft_with(n, 0, algorithm=algo)
+            except rustfft_amd.FftPanic as e:
+                out[name] = {"error": str(e)[:80]}
+                continue
             torch.view_as_real(x).uniform_(-1.0, 1.0)
             x0 = x[:n].cpu().numpy()
             fft.process(x)
@@ -49,6 +55,8 @@ def main():
             ms = sorted(ts)[1]
             out[name] = {"TBps": round(batch * 2 * n * esz / ms / 1e9, 3), "rel_l2": err, "plan": fft.describe()[:60]}
         out["auto_over_bluestein"] = round(out["auto"]["TBps"] / out["bluestein"]["TBps"], 2)
+        if args.rader and "TBps" in out.get("rader", {}):
+            out["rader_over_bluestein"] = round(out["rader"]["TBps"] / out["bluestein"]["TBps"], 2)
         print(json.dumps(out), flush=True)
         del x
 

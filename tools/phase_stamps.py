@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
-"""Phase timeline of the column-tile kernels from in-kernel timestamps (tuning probe builds only: DevExec::stamp,
-ABL bit 12; the library must export mi355fft_debug_read_stamps).  Wave 0 of every workgroup records s_memtime at kernel
-entry (0), when its first loads have landed (1), when the last sub-pass starts (2) and when its stores are acknowledged (3),
-plus HW_ID / XCC_ID.  Prints per-phase medians and the per-CU occupancy picture of the LAST kernel of the plan.
+"""Phase timeline of the column-tile kernels from in-kernel timestamps (tuning PROBE builds only: DevExec::stamp, ABL bit 12;
+the library must export mi355fft_debug_read_stamps -- see profiles/r3/stamp_probe.patch).  EVERY wave of the first 2048
+workgroups records s_memtime at: 0 kernel entry, 1 its first loads landed, 2 + 5P sub-pass P's arithmetic done,
+3..6 + 5P the four barriers of exchange P (after scatter re / gather re / scatter im / gather im), 13 its stores acknowledged.
+Prints, for the LAST kernel of the plan: the median time a wave spends between consecutive stamps, and for every stamp that
+follows a barrier the median skew between the first and the last wave of a workgroup reaching the PREVIOUS stamp (i.e. how
+long the early waves waited at that barrier).
 usage: python tools/phase_stamps.py --lib libmi355fft_exp.so --log2n 22 --batch 64 --variant 50"""
 import argparse
 import ctypes
 import json
 import os
-import statistics
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,6 +23,7 @@ def main():
     ap.add_argument("--log2n", type=int, default=22)
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--variant", type=int, default=50)
+    ap.add_argument("--waves", type=int, default=8, help="waves per workgroup of the last kernel")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -39,57 +42,29 @@ def main():
     for _ in range(3):
         fft.process_outofplace_with_scratch(x, y)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    fft.process_outofplace_with_scratch(x, y)
-    e1.record()
-    torch.cuda.synchronize()
-    nwg = 65536
-    buf = np.zeros(nwg * 8, dtype=np.uint64)
+    nwg, slots = 2048, 16
+    buf = np.zeros(nwg * 16 * slots, dtype=np.uint64)
     lib.mi355fft_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     rc = lib.mi355fft_debug_read_stamps(buf.ctypes.data, buf.nbytes)
     assert rc == 0, rc
-    s = buf.reshape(nwg, 8)
-    used = s[:, 0] != 0
-    s = s[used]
-    t = s[:, :4].astype(np.int64)
-    base = t[:, 0].min()
-    t -= base
-    span = int(t[:, 3].max())
-    ms_pair = e0.elapsed_time(e1)
+    s = buf.reshape(nwg, 16, slots)[:, :args.waves, :].astype(np.int64)
+    ids = [i for i in range(14) if (s[:, :, i] != 0).all()]
+    t = s[:, :, ids]
+    t = t - t[:, :, 0].min(axis=1)[:, None, None]  # per workgroup: relative to its first wave's entry
+    names = {0: "entry", 1: "loads_landed", 13: "stores_acked"}
+    for q in range(3):
+        names[2 + 5 * q] = f"sp{q}_arith_done"
+        for j, nm in enumerate(("scatter_re", "gather_re", "scatter_im", "gather_im")):
+            names[3 + 5 * q + j] = f"x{q}_barrier_after_{nm}"
     med = lambda a: float(np.median(a))
-    hw = s[:, 4].astype(np.int64)
-    xcc = s[:, 5].astype(np.int64) & 0xF
-    cu = (hw >> 8) & 0xF
-    sh = (hw >> 12) & 0x1
-    se = (hw >> 13) & 0x7
-    key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
-    out = {"plan": fft.describe(), "workgroups_recorded": int(used.sum()), "span_ticks_last_kernel": span, "pair_ms_all_kernels": ms_pair,
-           "median_ticks": {"load(0->1)": med(t[:, 1] - t[:, 0]), "compute_to_last_subpass(1->2)": med(t[:, 2] - t[:, 1]),
-                            "last_subpass+stores(2->3)": med(t[:, 3] - t[:, 2]), "total(0->3)": med(t[:, 3] - t[:, 0])},
-           "p10_p90_total": [float(np.percentile(t[:, 3] - t[:, 0], 10)), float(np.percentile(t[:, 3] - t[:, 0], 90))],
-           "distinct_cu_keys": int(len(set(key.tolist())))}
-    # per-CU: fraction of the span in which NO resident workgroup is between stamps 0..1 or 2..3 (i.e. nobody is moving data)
-    idle_frac, both_mem = [], []
-    for k in list(set(key.tolist()))[:64]:
-        rows = t[key == k]
-        ev = []
-        for r in rows:
-            ev.append((r[0], +1)); ev.append((r[1], -1)); ev.append((r[2], +1)); ev.append((r[3], -1))
-        ev.sort()
-        cur, last, idle, busy2 = 0, ev[0][0], 0, 0
-        for tt, d in ev:
-            if cur == 0:
-                idle += tt - last
-            if cur >= 2:
-                busy2 += tt - last
-            cur += d
-            last = tt
-        tot = ev[-1][0] - ev[0][0]
-        idle_frac.append(idle / max(tot, 1))
-        both_mem.append(busy2 / max(tot, 1))
-    out["per_cu_frac_time_no_workgroup_in_a_memory_phase"] = statistics.median(idle_frac)
-    out["per_cu_frac_time_two_workgroups_in_memory_phases"] = statistics.median(both_mem)
+    steps = {}
+    for i in range(len(ids) - 1):
+        d = t[:, :, i + 1] - t[:, :, i]
+        skew_prev = t[:, :, i].max(axis=1) - t[:, :, i].min(axis=1)
+        steps[f"{names[ids[i]]} -> {names[ids[i + 1]]}"] = {"median_wave": med(d), "fastest_wave": med(d.min(axis=1)), "slowest_wave": med(d.max(axis=1)),
+                                                           "skew_of_waves_at_start": med(skew_prev)}
+    total = t[:, :, -1].max(axis=1) - t[:, :, 0].min(axis=1)
+    out = {"plan": fft.describe(), "stamp_ids": ids, "steps_ticks": steps, "median_workgroup_total": med(total)}
     print(json.dumps(out))
 
 

@@ -29,7 +29,7 @@ def main():
         if len(sys.argv) > 1 and sys.argv[1] == "--sweep":  # python tools/pmc_sq.py --sweep --dtype f32 --sizes 1019
             target = [sys.executable, os.path.join(ROOT, "tools", "sweep.py"), "--reps", "2"] + sys.argv[2:]
         else:
-            target = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-pmc"] + sys.argv[1:]
+            target = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-pmc", "--no-side"] + sys.argv[1:]
         cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--"] + target
         r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=900, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:

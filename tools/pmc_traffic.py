@@ -28,7 +28,7 @@ def collect(bench_args, timeout=600):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="mi355pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--",
-               sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-pmc"] + list(bench_args)
+               sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-pmc", "--no-side"] + list(bench_args)
         subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
         acc = collections.defaultdict(list)

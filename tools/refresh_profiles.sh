@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 # 1. the bench line exactly as the driver runs it (roofline with PMC traffic + cpu_baseline)
 python bench.py > $OUT/bench_final.json 2> $OUT/bench_final.stderr
 # 2. rocprofv3 kernel trace + stats of the same command (PMC and CPU legs off: they would only add their own processes)
-( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_c2 -o c2 --output-format csv -- python $ROOT/bench.py --no-pmc --no-cpu-baseline > $OUT/bench_under_rocprof.json 2>/dev/null )
+( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_c2 -o c2 --output-format csv -- python $ROOT/bench.py --no-pmc --no-cpu-baseline --no-side > $OUT/bench_under_rocprof.json 2>/dev/null )
 cp $(find /tmp/prof_c2 -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv 2>/dev/null
 # 3. the other BASELINE configs
 for c in c3 c4 c5; do python bench.py --config $c --no-cpu-baseline > $OUT/bench_$c.json 2>/dev/null; done  # roofline.traffic from PMC included
