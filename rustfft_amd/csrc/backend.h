@@ -23,6 +23,9 @@ void* event_create();
 void event_destroy(void* e);
 void event_record(void* e, void* stream);
 float event_elapsed_ms(void* a, void* b);  // synchronises on b
+int event_sync(void* e);                   // blocks the calling thread until the event has completed
+void* stream_create();                     // non-blocking stream on the current device (the host-slice path's own streams)
+void stream_destroy(void* s);
 // read + write GB/s of the fastest plain copy this chip does (one float4 per thread, huge grid): the measured data-movement
 // ceiling bench.py quotes next to the 8 TB/s spec (MI355X_MICROARCH.md: 6.29 TB/s); 0 on failure
 double copy_ceiling_gbps(size_t bytes);

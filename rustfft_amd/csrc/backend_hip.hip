@@ -64,6 +64,15 @@ float event_elapsed_ms(void* a, void* b) {
     (void)hipEventElapsedTime(&ms, (hipEvent_t)a, (hipEvent_t)b);
     return ms;
 }
+int event_sync(void* e) { return fail(hipEventSynchronize((hipEvent_t)e)); }
+void* stream_create() {
+    hipStream_t s;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return (void*)s;
+}
+void stream_destroy(void* s) {
+    if (s) (void)hipStreamDestroy((hipStream_t)s);
+}
 typedef float copy_v4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void copy_f4_kernel(const copy_v4* __restrict__ in, copy_v4* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

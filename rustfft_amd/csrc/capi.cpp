@@ -1,7 +1,12 @@
 // extern "C" surface declared in include/mi355fft.h.
+#include <algorithm>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "backend.h"
 #include "plan.h"
@@ -54,7 +59,42 @@ void* stage(Workspace& w, size_t bytes) {
     return w.ptr;
 }
 
+// One upload and one download at a time per process: concurrent blocking pageable copies in the SAME direction thrash (four
+// threads at once: 29 - 37 GB/s of aggregate payload against 45 for one caller; tools/hostpath_bench.py), so the chunk copies of
+// concurrent host-slice calls take turns per direction while their kernels and the opposite direction overlap.
+std::mutex g_upload_turn, g_download_turn;
+
+// A staging context of the plan's pool for the duration of one host-slice call.
+struct HostLease {
+    Plan& plan;
+    Plan::HostCtx* ctx = nullptr;
+    explicit HostLease(Plan& p) : plan(p) {
+        std::lock_guard<std::mutex> g(plan.host_pool_mutex);
+        if (plan.host_pool.empty()) {
+            plan.host_busy.emplace_back(new Plan::HostCtx());
+        } else {
+            plan.host_busy.push_back(std::move(plan.host_pool.back()));
+            plan.host_pool.pop_back();
+        }
+        ctx = plan.host_busy.back().get();
+    }
+    ~HostLease() {
+        std::lock_guard<std::mutex> g(plan.host_pool_mutex);
+        for (size_t i = 0; i < plan.host_busy.size(); ++i)
+            if (plan.host_busy[i].get() == ctx) {
+                plan.host_pool.push_back(std::move(plan.host_busy[i]));
+                plan.host_busy.erase(plan.host_busy.begin() + (long)i);
+                break;
+            }
+    }
+};
+
 // host-slice path shared by the three trait methods.  mode as in execute().
+// Large calls run as a two-thread pipeline over row chunks: the calling thread uploads chunk c + 1 and enqueues its kernels
+// while a helper thread downloads chunk c, so both directions of the host link carry data at once (measured on the MI355X
+// box, tools/hostprobe: blocking pageable copies 56 GB/s up, 52 - 56 down, 27 - 28 GB/s of payload per round trip when one
+// follows the other; both directions at once 33 - 37 GB/s per direction, whether the caller's pages are registered or not --
+// the ceiling of this path; a CPU memcpy through pinned staging buffers reaches 15).
 int process_host(const mi355fft_plan* cplan, const void* in, size_t n_in, void* out, size_t n_out, size_t scratch_elems, int mode) {
     if (!cplan) return set_err(MI355FFT_ERR_INVALID_ARG, "null plan");
     Plan& plan = const_cast<Plan&>(cplan->p);
@@ -66,24 +106,106 @@ int process_host(const mi355fft_plan* cplan, const void* in, size_t n_in, void* 
     if (batch > 0) {
         if (!in || !out) return set_err(MI355FFT_ERR_INVALID_ARG, "null buffer");
         const size_t esz = plan.prec == 32 ? 8 : 16;
-        const size_t bytes = batch * len * esz;
-        // staging buffers, copies and the final sync all belong to the plan's device, whatever device is current in the
+        const size_t row = len * esz;
+        // staging buffers, streams, copies and syncs all belong to the plan's device, whatever device is current in the
         // calling thread (a fresh thread defaults to device 0)
         DeviceGuard dev(plan.device);
-        std::lock_guard<std::mutex> g(plan.host_mutex);
-        void* d_in = stage(plan.stage_a, bytes);
-        void* d_out = mode == 0 ? d_in : stage(plan.stage_b, bytes);
+        HostLease lease(plan);
+        Plan::HostCtx& cx = *lease.ctx;
+        if (!cx.stream_a) cx.stream_a = backend::stream_create();
+        if (!cx.stream_b) cx.stream_b = backend::stream_create();
+        if (!cx.stream_a || !cx.stream_b) return hip_err(MI355FFT_ERR_HIP);
+        // chunks of about 64 MiB (whole rows), two staging slots; small calls are one chunk
+        size_t kChunkBytes = (size_t)64 << 20;
+#if defined(MI355_TUNING) || defined(MI355_EMU)
+        if (const char* e = getenv("MI355FFT_HOST_CHUNK_KIB")) kChunkBytes = (size_t)atol(e) << 10;  // tests: a pipeline over small chunks
+#endif
+        size_t rows_per_chunk = std::max<size_t>(1, kChunkBytes / row);
+        if (batch * row <= kChunkBytes + kChunkBytes / 2) rows_per_chunk = batch;
+        const size_t nchunks = (batch + rows_per_chunk - 1) / rows_per_chunk;
+        const size_t slot_bytes = rows_per_chunk * row, nslots = nchunks > 1 ? 2 : 1;
+        char* d_in = (char*)stage(cx.in, slot_bytes * nslots);
+        char* d_out = mode == 0 ? d_in : (char*)stage(cx.out, slot_bytes * nslots);
         if (!d_in || !d_out) return set_err(MI355FFT_ERR_OUT_OF_MEMORY, "device staging allocation failed");
-        if (backend::h2d(d_in, in, bytes, nullptr)) return hip_err(MI355FFT_ERR_HIP);
-        int rc = execute(plan, d_in, d_out, batch, nullptr, mode, nullptr);
-        if (rc) return rc == MI355FFT_ERR_HIP ? hip_err(rc) : set_err(rc, "execution failed");
-        if (backend::d2h(out, d_out, bytes, nullptr)) return hip_err(MI355FFT_ERR_HIP);
-        if (mode == 1) {
-            // the reference's out-of-place variant leaves `input` in an unspecified state; mirror the device
-            // buffer back so host and device callers observe the same (clobbered) contents
-            if (backend::d2h(const_cast<void*>(in), d_in, bytes, nullptr)) return hip_err(MI355FFT_ERR_HIP);
+        std::vector<void*> done(nchunks, nullptr);
+        std::mutex m;
+        std::condition_variable cv;
+        size_t uploaded = 0, downloaded = 0;  // chunks whose kernels are enqueued / whose results are back on the host
+        int rc_main = MI355FFT_OK, rc_dl = MI355FFT_OK;
+        std::string err_dl;
+        bool abort_dl = false;
+        const int device = plan.device;
+        auto download = [&]() {
+            backend::set_device(device);
+            for (size_t c = 0; c < nchunks; ++c) {
+                {
+                    std::unique_lock<std::mutex> lk(m);
+                    cv.wait(lk, [&] { return uploaded > c || abort_dl; });
+                    if (abort_dl) return;
+                }
+                const size_t r0 = c * rows_per_chunk, rows = std::min(rows_per_chunk, batch - r0), slot = (c % nslots) * slot_bytes;
+                int rc = backend::event_sync(done[c]);
+                std::unique_lock<std::mutex> turn(g_download_turn);
+                if (!rc) rc = backend::d2h((char*)out + r0 * row, d_out + slot, rows * row, cx.stream_b);
+                // the reference's out-of-place variant leaves `input` in an unspecified state; mirror the device buffer back so
+                // host and device callers observe the same (clobbered) contents
+                if (!rc && mode == 1) rc = backend::d2h((char*)const_cast<void*>(in) + r0 * row, d_in + slot, rows * row, cx.stream_b);
+                if (!rc) rc = backend::sync(cx.stream_b);
+                turn.unlock();
+                std::lock_guard<std::mutex> lk(m);
+                if (rc) {
+                    rc_dl = MI355FFT_ERR_HIP;
+                    err_dl = backend::last_error();
+                }
+                downloaded = c + 1;
+                cv.notify_all();
+                if (rc) return;
+            }
+        };
+        std::thread helper;
+        if (nchunks > 1) helper = std::thread(download);
+        for (size_t c = 0; c < nchunks && rc_main == MI355FFT_OK; ++c) {
+            const size_t r0 = c * rows_per_chunk, rows = std::min(rows_per_chunk, batch - r0), slot = (c % nslots) * slot_bytes;
+            if (c >= nslots) {  // the slot's previous chunk must be back on the host first
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return downloaded + nslots > c || rc_dl != MI355FFT_OK; });
+                if (rc_dl != MI355FFT_OK) break;
+            }
+            {
+                std::lock_guard<std::mutex> turn(g_upload_turn);
+                if (backend::h2d(d_in + slot, (const char*)in + r0 * row, rows * row, cx.stream_a) || backend::sync(cx.stream_a)) {
+                    rc_main = hip_err(MI355FFT_ERR_HIP);
+                    break;
+                }
+            }
+            int rc = execute(plan, d_in + slot, d_out + slot, rows, cx.stream_a, mode, nullptr);
+            if (rc) {
+                rc_main = rc == MI355FFT_ERR_HIP ? hip_err(rc) : set_err(rc, "execution failed");
+                break;
+            }
+            done[c] = backend::event_create();
+            backend::event_record(done[c], cx.stream_a);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                uploaded = c + 1;
+            }
+            cv.notify_all();
         }
-        if (backend::sync(nullptr)) return hip_err(MI355FFT_ERR_HIP);
+        if (nchunks > 1) {
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (rc_main != MI355FFT_OK) abort_dl = true;
+            }
+            cv.notify_all();
+            helper.join();
+        } else if (rc_main == MI355FFT_OK) {
+            download();
+        }
+        backend::sync(cx.stream_a);
+        for (void* e : done)
+            if (e) backend::event_destroy(e);
+        if (rc_main != MI355FFT_OK) return rc_main;
+        if (rc_dl != MI355FFT_OK) return set_err(rc_dl, err_dl);
     }
     // a trailing partial chunk is reported after the complete chunks were transformed (array_utils.rs:164-176)
     if (rem != 0) return validation_error(len, n_in, n_out, false);

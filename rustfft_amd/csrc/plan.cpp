@@ -189,8 +189,13 @@ Plan::~Plan() {
     backend::sync_device();
     for (void* p : device_allocs) backend::dfree(p);
     for (auto& kv : slots) backend::dfree(kv.second->ws.ptr);
-    backend::dfree(stage_a.ptr);  // host-slice staging buffers
-    backend::dfree(stage_b.ptr);
+    for (auto* pool : {&host_pool, &host_busy})  // host-slice staging contexts
+        for (auto& c : *pool) {
+            backend::dfree(c->in.ptr);
+            backend::dfree(c->out.ptr);
+            backend::stream_destroy(c->stream_a);
+            backend::stream_destroy(c->stream_b);
+        }
 }
 
 template <class T> static void* upload(Plan& plan, const std::vector<T>& host, int* rc) {

@@ -89,8 +89,17 @@ struct Plan {
     int device = -1;  // HIP device the tables live on (the device current at creation)
     std::mutex ws_mutex;
     std::map<void*, std::unique_ptr<StreamSlot>> slots;  // one execution slot (HBM workspace) per stream
-    std::mutex host_mutex;                  // serialises the host-slice staging path
-    Workspace stage_a, stage_b;
+    // Host-slice path (mi355fft_process_*_host): a pool of staging contexts -- device buffers + two private streams each.  A
+    // calling thread takes one for the duration of its call (and makes a new one when all are busy), so host threads that share a
+    // plan (examples/concurrency.rs:9-30) stage, transform and copy back concurrently instead of queueing on one mutex.
+    struct HostCtx {
+        Workspace in, out;
+        void* stream_a = nullptr;  // uploads + kernels
+        void* stream_b = nullptr;  // downloads (a second thread drives them, so both directions of the link are busy)
+    };
+    std::mutex host_pool_mutex;
+    std::vector<std::unique_ptr<HostCtx>> host_pool;   // idle contexts
+    std::vector<std::unique_ptr<HostCtx>> host_busy;   // contexts lent to a call (kept here so the destructor sees them all)
     std::unique_ptr<Plan> inner;  // PLAN_BLUESTEIN_LARGE: forward power-of-two plan of the padded length M
 
     ~Plan();

@@ -30,6 +30,9 @@ void* event_create() { return (void*)1; }
 void event_destroy(void*) {}
 void event_record(void*, void*) {}
 float event_elapsed_ms(void*, void*) { return 0.f; }
+int event_sync(void*) { return 0; }
+void* stream_create() { return (void*)2; }
+void stream_destroy(void*) {}
 double copy_ceiling_gbps(size_t) { return 0.0; }
 }  // namespace backend
 }  // namespace mi355

@@ -702,6 +702,54 @@ def test_large_primes_vs_oracle(planners, oracle, dtype):
             assert rel_l2(y, numpy_fft(x, p, d == 1)) < REL[np.dtype(dtype)], (p, d, fft.describe())
 
 
+def test_host_slices_pipeline_and_shared_plan_threads(planners, oracle):
+    """The literal drop-in path on the device: a 384 MiB host slice (six staging chunks: upload + kernels on the calling thread,
+    download on the helper thread) in all three API modes against the one-chunk result of the same rows, and four host threads
+    sharing one two-pass plan (examples/concurrency.rs:9-30), each through its own staging context, every row against the oracle."""
+    import threading
+
+    planner = planners[np.dtype(np.complex64)]
+    n, batch = 1 << 16, 768
+    fft = planner.plan_fft_forward(n)
+    x = zero_mean_signal(n * batch, np.complex64, seed=16)
+    y = x.copy()
+    fft.process(y)
+    for r in (0, 1, 127, 128, 383, 767):
+        want = x[r * n:(r + 1) * n].copy()
+        oracle.plan(np.complex64, n, 0).process(want)
+        assert rel_l2(y[r * n:(r + 1) * n], want) < REL[np.dtype(np.complex64)], r
+    small = x[: 8 * n].copy()
+    fft.process(small)  # one chunk
+    assert np.array_equal(small, y[: 8 * n])
+    out = np.zeros_like(x)
+    fft.process_immutable_with_scratch(x, out)
+    assert np.array_equal(out, y)
+    src, out2 = x.copy(), np.zeros_like(x)
+    fft.process_outofplace_with_scratch(src, out2)
+    assert np.array_equal(out2, y)
+    xs = [zero_mean_signal(n * 40, np.complex64, seed=100 + i) for i in range(4)]
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(2):
+                z = xs[i].copy()
+                fft.process(z)
+                for r in (0, 39):
+                    want = xs[i][r * n:(r + 1) * n].copy()
+                    oracle.plan(np.complex64, n, 0).process(want)
+                    assert rel_l2(z[r * n:(r + 1) * n], want) < REL[np.dtype(np.complex64)]
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+
+
 def test_config2_full_batch_every_row(planners):
     """BASELINE config 2 at its full size, every row: per-row Parseval (a mis-twiddled row keeps its element sum but not its
     energy spectrum's consistency with a second check) and 64 rows drawn at random over the whole batch against numpy

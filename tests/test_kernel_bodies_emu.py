@@ -81,6 +81,58 @@ def test_chunked_workspace_matches_unchunked(emu_planner):
     assert np.array_equal(a, b)
 
 
+def test_host_slices_chunk_pipeline_and_threads(emu_planner, oracle):
+    """The host-slice path (capi.cpp process_host): a call larger than one staging chunk runs as a two-thread pipeline over row
+    chunks (upload + kernels on the calling thread, download on a helper) through a staging context of the plan's pool; four
+    threads sharing one plan (examples/concurrency.rs:9-30) each take their own context.  All three API modes, ragged last
+    chunk, a multi-pass plan (workspace per context stream), results identical to the one-chunk path."""
+    import threading
+
+    os.environ["MI355FFT_HOST_CHUNK_KIB"] = "64"
+    try:
+        planner = emu_planner(np.complex64)
+        for n, batch in ((1024, 37), (1 << 16, 5), (1009, 23)):
+            fft = planner.plan_fft_forward(n)
+            x = zero_mean_signal(n * batch, np.complex64, seed=n)
+            want = x.copy()
+            oracle.plan(np.complex64, n, 0).process(want)
+            y = x.copy()
+            fft.process(y)
+            assert rel_l2(y, want) < 2e-6
+            out = np.zeros_like(x)
+            fft.process_immutable_with_scratch(x, out)
+            assert np.array_equal(out, y)
+            src, out2 = x.copy(), np.zeros_like(x)
+            fft.process_outofplace_with_scratch(src, out2)
+            assert np.array_equal(out2, y)
+        fft = planner.plan_fft_forward(1024)
+        xs = [zero_mean_signal(1024 * 29, np.complex64, seed=s) for s in range(4)]
+        wants = []
+        for x in xs:
+            w = x.copy()
+            oracle.plan(np.complex64, 1024, 0).process(w)
+            wants.append(w)
+        errs = []
+
+        def work(i):
+            try:
+                for _ in range(3):
+                    y = xs[i].copy()
+                    fft.process(y)
+                    assert rel_l2(y, wants[i]) < 2e-6
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errs, errs
+    finally:
+        del os.environ["MI355FFT_HOST_CHUNK_KIB"]
+
+
 def test_validation_semantics(emu_planner):
     """src/common.rs:13-104 messages; partial trailing chunk reported AFTER the complete chunks ran
     (src/array_utils.rs:164-176); empty buffer accepted; len 0 is a no-op (src/fft_helper.rs:16-18)."""
