@@ -367,6 +367,93 @@ MI_HD void k2g_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     wg_fft<T, S, F, MAP_FF, FIRST ? MAP_EF : MAP_FF, SPLIT, false, k2_pitch_mod(F), 0, -1, false, (S::NP >= 2 ? TWL : 0)>(ex, lds, p.tw, src, dst);
 }
 
+// ---- large-N pass whose tile height is a PRIME P: Rader inside the tile ----------------------------------------------------
+// The six-step MixedRadix of the reference (src/algorithm/mixed_radix.rs:53-158) for lengths with prime factors above 31
+// (37 x 41, 101 x 103 ...: src/plan.rs:474-506 plans them as MixedRadix over Rader / Bluestein inner FFTs).  Same pass law as
+// k2g_body -- a workgroup owns F adjacent columns, in_j = X[B + j M] w_{S P}^{(B mod S) j}, out_k -> Y[(B div S) S P + (B mod S) + k S]
+// -- but the length-P column transform is Rader's algorithm (raders_algorithm.rs:235-283) run on the tile in LDS exactly as
+// rader_body MODE 1 runs it on contiguous rows: the strided load scatters row j of every column to its convolution slot
+// (perm = the inverse map j -> slot, x[0] to a spare slot), two inner transforms of length P - 1 with the spectrum multiply in
+// between, the second one scattering to natural order, then the strided (first pass: contiguous) store.  HBM sees each element
+// of the pass once, in F-element row segments, like every other column-tile pass.
+template <class T, class S, int F, bool FIRST, class X>
+MI_HD void k2r_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
+    constexpr int Mi = S::N, P = S::N + 1, PITCH = S::pitch(), NT = F * S::TPF;
+    // x[0], then X[0]: a slot past both the exchange span and the natural-order outputs (see rader_body MODE 1)
+    constexpr int XS = (S::phys(Mi - 1) + 1 > P) ? S::phys(Mi - 1) + 1 : P;
+    static_assert(XS < PITCH && P <= PITCH, "row pitch must leave a spare slot");
+    const unsigned tpf = (unsigned)p.tiles_per_fft;
+    const long long g = (long long)((unsigned)block / tpf);  // grid <= 2^31 - 1 (plan.cpp kMaxGrid)
+    const unsigned b0 = ((unsigned)block - (unsigned)g * tpf) * (unsigned)F;
+    const cx<T>* in = p.in + g * p.n;
+    cx<T>* out = p.out + g * p.n;
+    const unsigned M = (unsigned)p.m, Sg = (unsigned)p.s;
+    const T sgn_in = p.sgn_in, sgn_out = p.sgn_out;
+    const cx<T>* MI_RESTRICT dtab = p.tab;
+    const cx<T>* MI_RESTRICT tlo = p.tlo;
+    const cx<T>* MI_RESTRICT thi = p.thi;
+    const int hshift = p.hshift, lmask = p.lmask;
+    const int* MI_RESTRICT perm_in = p.perm;
+    const int* MI_RESTRICT perm_out = p.perm2;
+    cx<T>* work = (cx<T>*)lds;
+    // lanes walk across the tile's columns: thread t holds column t % F and the rows t / F, t / F + TPF, ...
+    ex.for_threads([&](int tid, cx<T>*) {
+        const unsigned c = (unsigned)tid % (unsigned)F, B = b0 + c, col = B < M ? B : 0;  // masked columns read column 0 (never stored)
+        const unsigned cs = FIRST ? 0u : col % Sg;
+        for (unsigned r = (unsigned)tid / (unsigned)F; r < (unsigned)P; r += (unsigned)S::TPF) {
+            cx<T> x = in[col + r * M];
+            x.im *= sgn_in;
+            if constexpr (!FIRST) {
+                const unsigned e = cs * r;
+                x = x * (tlo[e & (unsigned)lmask] * thi[e >> hshift]);
+            }
+            work[c * PITCH + (r == 0 ? (unsigned)XS : (unsigned)perm_in[r])] = x;
+        }
+    });
+    ex.barrier();
+    auto src1 = [=](int f, int j) -> cx<T> { return work[f * PITCH + j]; };
+    auto dst1 = [=](int f, int j, cx<T> v) {
+        cx<T> t = cconj(v * dtab[j]);
+        if (j == 0) {
+            const cx<T> x0 = work[f * PITCH + XS];
+            t = t + cconj(x0);
+            work[f * PITCH + XS] = x0 + v;  // X[0]
+        }
+        work[f * PITCH + j] = t;
+    };
+    wg_fft<T, S, F, MAP_EF, MAP_EF, false, true>(ex, lds, p.tw, elem_src(src1), dst1);
+    ex.barrier();
+    auto dst2 = [=](int f, int j, cx<T> v) {
+        if (j == 0) work[f * PITCH] = work[f * PITCH + XS];  // slot 0 is no target of the g^-j scatter
+        work[f * PITCH + perm_out[j]] = cconj(v);
+    };
+    wg_fft<T, S, F, MAP_EF, MAP_EF, false, true>(ex, lds, p.tw, elem_src(src1), dst2);
+    ex.barrier();
+    ex.for_threads([&](int tid, cx<T>*) {
+        if constexpr (FIRST) {  // the tile's F x P outputs are one contiguous block: lanes walk along it
+            for (int t = tid; t < F * P; t += NT) {
+                const int f = t / P, i = t - f * P;
+                if (b0 + (unsigned)f < M) {
+                    cx<T> y = work[f * PITCH + i];
+                    y.im *= sgn_out;
+                    out[b0 * (unsigned)P + (unsigned)t] = y;
+                }
+            }
+        } else {
+            const unsigned c = (unsigned)tid % (unsigned)F, B = b0 + c;
+            if (B < M) {
+                const unsigned obase = (B / Sg) * (Sg * (unsigned)P) + (B % Sg);
+                for (unsigned k = (unsigned)tid / (unsigned)F; k < (unsigned)P; k += (unsigned)S::TPF) {
+                    cx<T> y = work[c * PITCH + k];
+                    y.im *= sgn_out;
+                    out[obase + k * Sg] = y;
+                }
+            }
+        }
+    });
+}
+template <class T, class S, int F> constexpr size_t k2r_lds_bytes() { return (size_t)F * S::pitch() * sizeof(cx<T>); }
+
 // ---- Bluestein: any length n <= (M + 1) / 2 through two length-M workgroup transforms ---------------------
 // The second transform runs the REVERSED schedule (engine.h reversed_sched): the first one leaves X[b + k M/R] in the
 // registers of the thread that needs exactly those values as inputs of its first radix-R butterflies, so the spectrum

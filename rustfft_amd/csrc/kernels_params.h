@@ -40,6 +40,7 @@ template <class T> struct K2Params {
     // n_io = p): FUSE 4 loads x[perm[idx]] (perm = g^(j+1) mod p); FUSE 5 stores conj(X * tab) (tab = d), adds conj(x[0]) to
     // element 0 and writes X[0] = x[0] + S[0] into the caller's output row; FUSE 6 stores conj(X) at perm[e] (perm = g^-(j+1) mod p)
     const int* perm;
+    const int* perm2;  // k2r_body (prime tile heights): g^-(j+1) mod P; `perm` holds the inverse map t -> j with g^(j+1) = t, `tab` d[P-1]
     const cx<T>* xin;  // the caller's input rows (x[0] of every row)
     cx<T>* xout;       // the caller's output rows (X[0] of every row)
     T sgn_x;           // -1 for the inverse plan (conj on the way in and out), +1 otherwise: every pass of the sequence sees it

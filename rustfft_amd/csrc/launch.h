@@ -267,6 +267,33 @@ template <class T, class S, int F, bool FIRST, int FUSE = 0, bool SPLIT = false,
     };
     return e;
 }
+template <class T, class S, int F, bool FIRST>
+__global__ __launch_bounds__(F* S::TPF) void k2r_kernel(K2Params<T> p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevExec<T, regs_needed<S, false>()> ex;
+    k2r_body<T, S, F, FIRST>(ex, p, (long long)blockIdx.x, smem);
+}
+template <class T, class S, int F, bool FIRST> KernelEntry make_k2r(int prec, const char* name) {
+    KernelEntry e{};
+    e.kind = FIRST ? KIND_K2R_FIRST : KIND_K2R_LATER;
+    e.prec = prec;
+    e.n = S::N + 1;  // the tile height: the prime
+    e.aux = S::N + 1;
+    e.f = F;
+    fill_sched<S>(e);
+    e.threads = F * S::TPF;
+    e.lds_bytes = k2r_lds_bytes<T, S, F>();
+    e.name = name;
+    e.launch = [](const void* params, long long grid, void* stream) {
+        void* args[] = {const_cast<void*>(params)};
+        (void)hipLaunchKernel((const void*)k2r_kernel<T, S, F, FIRST>, dim3((unsigned)grid), dim3(F * S::TPF), args, k2r_lds_bytes<T, S, F>(),
+                              (hipStream_t)stream);
+    };
+    e.prepare = []() -> int {
+        return (int)hipFuncSetAttribute((const void*)k2r_kernel<T, S, F, FIRST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2r_lds_bytes<T, S, F>());
+    };
+    return e;
+}
 constexpr int kDynEmax = 16, kDynEmaxLight = 12, kDynEmaxHeavy = 32;
 constexpr int dyn_emax(int set) { return set == 1 ? kDynEmaxLight : set == 2 ? kDynEmaxHeavy : kDynEmax; }
 // the HEAVY set (prime radices 17 .. 31, 32 values per thread) runs workgroups of at most 256 threads: 256 VGPRs each
@@ -502,6 +529,27 @@ template <class T, class S, int F, bool FIRST, int FUSE = 0, bool SPLIT = false,
     e.prepare = []() -> int { return 0; };
     return e;
 }
+template <class T, class S, int F, bool FIRST> KernelEntry make_k2r(int prec, const char* name) {
+    KernelEntry e{};
+    e.kind = FIRST ? KIND_K2R_FIRST : KIND_K2R_LATER;
+    e.prec = prec;
+    e.n = S::N + 1;
+    e.aux = S::N + 1;
+    e.f = F;
+    fill_sched<S>(e);
+    e.threads = F * S::TPF;
+    e.lds_bytes = k2r_lds_bytes<T, S, F>();
+    e.name = name;
+    e.launch = [](const void* params, long long grid, void*) {
+        std::vector<char> lds(k2r_lds_bytes<T, S, F>() + 64, (char)0x5a);
+        for (long long b = 0; b < grid; ++b) {
+            HostExec<T, regs_needed<S, false>()> ex(F * S::TPF);
+            k2r_body<T, S, F, FIRST>(ex, *(const K2Params<T>*)params, b, lds.data());
+        }
+    };
+    e.prepare = []() -> int { return 0; };
+    return e;
+}
 constexpr int kDynEmax = 16, kDynEmaxLight = 12, kDynEmaxHeavy = 32;
 template <class T> KernelEntry make_dyn_k1(int prec) {
     KernelEntry e{};
@@ -619,6 +667,10 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
     reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, true, 4>(PREC, "k2gfirst_gather<" #__VA_ARGS__ ">xF" #F));  \
     reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, false, 5>(PREC, "k2glast_rmul<" #__VA_ARGS__ ">xF" #F));    \
     reg.push_back(make_k2g<T, Sched<__VA_ARGS__>, F, false, 6>(PREC, "k2glast_scatter<" #__VA_ARGS__ ">xF" #F))
+// column-tile passes of a prime tile height (Rader inside the tile); the Sched is the inner length P - 1
+#define MI_K2R(T, PREC, F, ...)                                                                  \
+    reg.push_back(make_k2r<T, Sched<__VA_ARGS__>, F, true>(PREC, "k2rfirst<" #__VA_ARGS__ ">xF" #F)); \
+    reg.push_back(make_k2r<T, Sched<__VA_ARGS__>, F, false>(PREC, "k2rlater<" #__VA_ARGS__ ">xF" #F))
 // Bluestein bodies take the linear exchange layout (SchedL): 164 -> 124 VGPRs for the power-of-two inner lengths
 #define MI_BS(T, PREC, F, ...) reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F))
 // one-kernel Bluestein through the split exchange (padded lengths above 8192: one workgroup per row)

@@ -68,6 +68,8 @@ void ensure_registry() {
         register_k2gr_f64_1(r);
         register_k2gr_f64_2(r);
         register_k2gr_f64_3(r);
+        register_k2r_f32(r);
+        register_k2r_f64(r);
         register_smooth_f32_0(r);
         register_smooth_f32_1(r);
         register_smooth_f32_2(r);
@@ -470,7 +472,7 @@ static bool choose_macro_radices(int prec, size_t n, std::vector<size_t>& out) {
 static bool choose_general_radices(int prec, size_t n, std::vector<size_t>& out) {
     std::vector<size_t> avail;
     for (auto& e : registry())
-        if (e.kind == KIND_K2G_FIRST && e.prec == prec) avail.push_back(e.n);
+        if ((e.kind == KIND_K2G_FIRST || (e.kind == KIND_K2R_FIRST && env_int("MI355FFT_NO_K2R") == 0)) && e.prec == prec) avail.push_back(e.n);
     std::sort(avail.begin(), avail.end(), std::greater<size_t>());
     std::vector<size_t> best, cur;
     size_t best_max = 0;
@@ -518,6 +520,7 @@ template <class T> static int build_lohi(Plan& plan, PassDesc& pd, size_t Q) {
 
 // Passes of one length-N transform over the general column-tile kernels; kinds[p] names the kernel family of pass p
 // (plain first / later, or one of the fused Bluestein passes).
+template <class T> static int rader_tables(Plan& plan, PassDesc& pd, bool inverse_map_in, size_t prime);
 template <class T>
 static int append_general_passes(Plan& plan, size_t N, const std::vector<size_t>& radices, const std::vector<int>& kinds, void* tab_first,
                                  void* tab_last) {
@@ -526,6 +529,9 @@ static int append_general_passes(Plan& plan, size_t N, const std::vector<size_t>
     for (size_t p = 0; p < radices.size(); ++p) {
         const size_t R = radices[p];
         const KernelEntry* k = find_kernel(kinds[p], plan.prec, R);
+        // a prime tile height: Rader inside the tile (plain passes only: the fused Bluestein / Rader sequences use smooth heights)
+        const bool prime_tile = !k && (kinds[p] == KIND_K2G_FIRST || kinds[p] == KIND_K2G_LATER);
+        if (prime_tile) k = find_kernel(kinds[p] == KIND_K2G_FIRST ? KIND_K2R_FIRST : KIND_K2R_LATER, plan.prec, R);
         if (!k) return MI355FFT_ERR_UNSUPPORTED;
         if (k->prepare()) return MI355FFT_ERR_HIP;
         PassDesc pd{};
@@ -534,6 +540,7 @@ static int append_general_passes(Plan& plan, size_t N, const std::vector<size_t>
         pd.s = (long long)s;
         pd.row_n = (long long)N;
         pd.d_aux1 = (p == 0) ? tab_first : (p + 1 == radices.size()) ? tab_last : nullptr;
+        if (prime_tile && (rc = rader_tables<T>(plan, pd, true, R))) return rc;  // d[R - 1], the inverse gather map, g^-(j+1)
         pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(*k), &rc);
         if (rc) return rc;
         if (p > 0 && (rc = build_lohi<T>(plan, pd, s * R))) return rc;
@@ -596,8 +603,8 @@ template <class T> static std::vector<cd> from_host_table(const void* p, size_t 
 }
 
 // Rader tables (raders_algorithm.rs:65-124): d[j] = FFT_{p-1}(twiddle(g^-j mod p, p)) / (p - 1), g^(j+1), g^-(j+1)
-template <class T> static int rader_tables(Plan& plan, PassDesc& pd, bool inverse_map_in) {
-    const uint64_t pp = plan.len, g = primitive_root(pp), ginv = modpow(g, pp - 2, pp);
+template <class T> static int rader_tables(Plan& plan, PassDesc& pd, bool inverse_map_in, size_t prime) {
+    const uint64_t pp = prime ? prime : plan.len, g = primitive_root(pp), ginv = modpow(g, pp - 2, pp);
     std::vector<cd> d(pp - 1);
     std::vector<int> pin(pp - 1), pout(pp - 1);
     uint64_t ti = 1, a = 1, b = 1;
@@ -611,7 +618,7 @@ template <class T> static int rader_tables(Plan& plan, PassDesc& pd, bool invers
         pin[j] = (int)a;
         pout[j] = (int)b;
     }
-    if (plan.opt_rader)
+    if (plan.opt_rader && pp == plan.len)  // the host planner's table belongs to the plan's own length
         d = from_host_table<T>(plan.opt_rader, pp - 1, plan.direction == MI355FFT_INVERSE);
     else
         host_dft(d);
@@ -771,8 +778,17 @@ template <class T> static int build_plan_t(Plan& plan) {
             }
             return MI355FFT_OK;
         }
-        // composite lengths above one workgroup whose factors are 2, 3, 5, 7: two to four general passes (k2g_body)
-        if (n > 4096 && n < ((size_t)1 << 31) && choose_general_radices(plan.prec, n, radices)) {
+        // composite lengths above one workgroup: two to four general passes over 13-smooth tile heights (k2g_body) and prime tile
+        // heights 37 .. 631 (k2r_body: Rader inside the tile) -- the reference's MixedRadix over Rader inner FFTs for lengths such
+        // as 101 x 103 (src/plan.rs:474-506).  At or below 4096 (37 x 41: the one-kernel Bluestein moves each row once) only a host
+        // planner's MixedRadix recipe takes the prime tiles.
+        bool general = n < ((size_t)1 << 31) && choose_general_radices(plan.prec, n, radices);
+        if (general && n <= 4096) {
+            bool prime_tile = false;
+            for (size_t r : radices) prime_tile = prime_tile || (r > 31 && is_prime_sz(r));
+            general = prime_tile && (algo == MI355FFT_ALGO_MIXED_RADIX || env_int("MI355FFT_K2R_SMALL") == 1);
+        }
+        if (general) {
             plan.kind = PLAN_MACRO;
             std::vector<int> kinds(radices.size(), KIND_K2G_LATER);
             kinds[0] = KIND_K2G_FIRST;
@@ -796,7 +812,7 @@ template <class T> static int build_plan_t(Plan& plan) {
             pd.k = &e;
             pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(e), &rc);
             if (rc) return rc;
-            if ((rc = rader_tables<T>(plan, pd, e.split))) return rc;  // e.split: MODE >= 1 bodies scatter on load
+            if ((rc = rader_tables<T>(plan, pd, e.split, 0))) return rc;  // e.split: MODE >= 1 bodies scatter on load
             plan.passes.push_back(pd);
             return MI355FFT_OK;
         }
@@ -814,7 +830,7 @@ template <class T> static int build_plan_t(Plan& plan) {
         if (choose_general_radices(plan.prec, n - 1, radices) && find_kernel(KIND_K2G_FIRST_GATHER, plan.prec, radices.front()) &&
             find_kernel(KIND_K2G_LAST_RMUL, plan.prec, radices.back()) && find_kernel(KIND_K2G_LAST_SCATTER, plan.prec, radices.back())) {
             PassDesc tabs{};
-            if ((rc = rader_tables<T>(plan, tabs, false))) return rc;
+            if ((rc = rader_tables<T>(plan, tabs, false, 0))) return rc;
             const size_t P = radices.size();
             std::vector<int> k1(P, KIND_K2G_LATER), k2(P, KIND_K2G_LATER);
             k1[0] = KIND_K2G_FIRST_GATHER;
@@ -864,7 +880,7 @@ template <class T> static int build_plan_t(Plan& plan) {
             pd.dyn = ds;
             pd.d_tw = upload<T>(plan, build_dyn_twiddles<T>(ds), &rc);
             if (rc) return rc;
-            if ((rc = rader_tables<T>(plan, pd, false))) return rc;
+            if ((rc = rader_tables<T>(plan, pd, false, 0))) return rc;
             plan.passes.push_back(pd);
             return MI355FFT_OK;
         }
@@ -1133,13 +1149,14 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         p.s = pd.s;
         p.batch = (long long)batch;
         p.tab = (const cx<T>*)pd.d_aux1;  // fused Bluestein / Rader passes only
-        p.perm = (const int*)pd.d_perm_in;  // fused Rader: g^(j+1) on the gather pass, g^-(j+1) on the scatter pass
+        p.perm = (const int*)pd.d_perm_in;  // fused Rader: g^(j+1) on the gather pass, g^-(j+1) on the scatter pass; prime tiles: both maps
+        p.perm2 = (const int*)pd.d_perm_out;
         p.xin = (const cx<T>*)xin;
         p.xout = (cx<T>*)xout;
         p.sgn_x = inverse ? (T)-1 : (T)1;
         p.n_io = (long long)plan.len;
         p.n_valid = (unsigned)plan.len;
-        const bool general = (k.kind == KIND_K2G_FIRST || k.kind == KIND_K2G_LATER || k.kind >= KIND_K2G_FIRST_CHIRP);
+        const bool general = (k.kind == KIND_K2G_FIRST || k.kind == KIND_K2G_LATER || k.kind >= KIND_K2G_FIRST_CHIRP);  // incl. the prime tiles
         p.tiles_per_fft = general ? (pd.m + k.f - 1) / k.f : pd.m / k.f;
         p.sgn_in = (inverse && pi == 0) ? (T)-1 : (T)1;
         p.sgn_out = (inverse && pi + 1 == plan.passes.size()) ? (T)-1 : (T)1;

@@ -15,7 +15,9 @@ enum KernelKind { KIND_K1 = 1, KIND_K2_FIRST = 2, KIND_K2_LATER = 3, KIND_RADER 
                   // multi-kernel Rader for primes beyond one workgroup (k2g_body FUSE = 4, 5, 6): the g^j gather rides on the first
                   // load of the first inner transform, the spectrum multiply + x[0] / X[0] step on its last store, the g^-j
                   // scatter on the last store of the second one
-                  KIND_K2G_FIRST_GATHER = 16, KIND_K2G_LAST_RMUL = 17, KIND_K2G_LAST_SCATTER = 18 };
+                  KIND_K2G_FIRST_GATHER = 16, KIND_K2G_LAST_RMUL = 17, KIND_K2G_LAST_SCATTER = 18,
+                  // column-tile passes whose tile height is a PRIME: Rader inside the tile (k2r_body); n = the prime
+                  KIND_K2R_FIRST = 19, KIND_K2R_LATER = 20 };
 
 struct KernelEntry {
     int kind;
@@ -71,6 +73,8 @@ void register_k2gr_f64_0(std::vector<KernelEntry>&);
 void register_k2gr_f64_1(std::vector<KernelEntry>&);
 void register_k2gr_f64_2(std::vector<KernelEntry>&);
 void register_k2gr_f64_3(std::vector<KernelEntry>&);
+void register_k2r_f32(std::vector<KernelEntry>&);  // generated: prime tile heights (tools/gen_k2g_kernels.py)
+void register_k2r_f64(std::vector<KernelEntry>&);
 // generated: compiled schedules for the 13-smooth lengths in (16, 4096] (tools/gen_smooth_kernels.py)
 void register_smooth_f32_0(std::vector<KernelEntry>&);
 void register_smooth_f32_1(std::vector<KernelEntry>&);

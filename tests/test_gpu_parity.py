@@ -702,6 +702,32 @@ def test_large_primes_vs_oracle(planners, oracle, dtype):
             assert rel_l2(y, numpy_fft(x, p, d == 1)) < REL[np.dtype(dtype)], (p, d, fft.describe())
 
 
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_prime_tile_heights_vs_oracle(planners, oracle, dtype):
+    """Composite lengths whose prime factors exceed 31 (the reference: MixedRadix over Rader inner FFTs, src/plan.rs:474-506,
+    mixed_radix.rs:53-158) as column-tile passes with PRIME tile heights -- Rader inside the tile (k2r_body): 101 x 103, a prime
+    tile beside a smooth one, three passes, ragged columns; 37 x 41 and 59 x 61 through a host planner's MixedRadix recipe (AUTO
+    keeps the one-kernel Bluestein at or below 4096).  Against the oracle's plan and numpy complex128, both directions."""
+    import rustfft_amd
+
+    planner = planners[np.dtype(dtype)]
+    for n in (101 * 103, 64 * 131, 37 * 41 * 43, 47 * 229, 89 * 97, 251 * 631):
+        for d in (0, 1):
+            fft = planner.plan_fft(n, d)
+            assert ("k2rfirst<" in fft.describe() or "k2rlater<" in fft.describe()) and "bluestein" not in fft.describe(), fft.describe()
+            check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=2)
+            x = zero_mean_signal(n * 3, dtype, seed=n)
+            y = x.copy()
+            fft.process(y)
+            assert rel_l2(y, numpy_fft(x, n, d == 1)) < REL[np.dtype(dtype)], (n, d, fft.describe())
+    for n in (37 * 41, 59 * 61):
+        assert "bluestein" in planner.plan_fft(n, 0).describe()
+        for d in (0, 1):
+            fft = planner.plan_fft_with(n, d, algorithm=rustfft_amd.ALGO_MIXED_RADIX)
+            assert fft.describe().startswith("k2rfirst<") and " -> k2rlater<" in fft.describe(), fft.describe()
+            check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=3)
+
+
 def test_host_slices_pipeline_and_shared_plan_threads(planners, oracle):
     """The literal drop-in path on the device: a 384 MiB host slice (six staging chunks: upload + kernels on the calling thread,
     download on the helper thread) in all three API modes against the one-chunk result of the same rows, and four host threads

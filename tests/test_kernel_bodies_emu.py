@@ -321,6 +321,30 @@ def test_large_prime_rader(emu_planner, oracle, dtype):
 
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_prime_tile_heights(emu_planner, oracle, dtype):
+    """Composite lengths with prime factors above 31 (the reference plans MixedRadix over Rader / Bluestein inner FFTs for them,
+    src/plan.rs:474-506, src/algorithm/mixed_radix.rs:53-158): column-tile passes whose tile height is the prime, Rader inside
+    the tile (kernels.h k2r_body).  101 x 103 (both passes prime tiles, 102 = 2 * 3 * 17: a prime-radix inner schedule), a prime
+    tile next to a smooth one (64 x 131), three passes (37 * 41 * 43), a ragged batch of columns (47 x 229: 229 columns are no
+    multiple of the tile width), and 37 x 41 the way a host planner asks for it (AUTO keeps the one-kernel Bluestein there)."""
+    import rustfft_amd
+
+    planner = emu_planner(dtype)
+    for n in (101 * 103, 64 * 131, 37 * 41 * 43, 47 * 229, 89 * 97):
+        for d in (0, 1):
+            fft = planner.plan_fft(n, d)
+            assert "k2rfirst<" in fft.describe() or "k2rlater<" in fft.describe(), fft.describe()
+            assert "bluestein" not in fft.describe(), fft.describe()
+            check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=2)
+    n = 37 * 41
+    assert "bluestein" in planner.plan_fft(n, 0).describe()
+    for d in (0, 1):
+        fft = planner.plan_fft_with(n, d, algorithm=rustfft_amd.ALGO_MIXED_RADIX)
+        assert fft.describe().startswith("k2rfirst<") and " -> k2rlater<" in fft.describe(), fft.describe()
+        check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=3)
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_general_column_tile_passes(emu_planner, oracle, dtype):
     """7-smooth lengths above one workgroup (kernels.h k2g_body): 2, 3 and 4 passes, tile heights that do not divide
     the strides (per-column b mod s), ragged last tiles (M not a multiple of F), pure powers of 3 and 5.  The

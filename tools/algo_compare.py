@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--bytes", type=float, default=1.0)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--mixed", action="store_true", help="extra arm: the plan a host planner gets with MI355FFT_ALGO_MIXED_RADIX (column-tile passes)")
     ap.add_argument("--rader", action="store_true", help="third arm: the plan a host planner gets with MI355FFT_ALGO_RADER (primes only)")
     args = ap.parse_args()
     import numpy as np
@@ -29,7 +30,7 @@ def main():
         batch = max(1, int(args.bytes * 2**30) // (n * esz))
         x = torch.empty(batch * n, dtype=tdt, device="cuda")
         out = {"n": n, "dtype": args.dtype, "batch": batch}
-        arms = [("auto", rustfft_amd.ALGO_AUTO), ("bluestein", rustfft_amd.ALGO_BLUESTEIN)] + ([("rader", rustfft_amd.ALGO_RADER)] if args.rader else [])
+        arms = [("auto", rustfft_amd.ALGO_AUTO), ("bluestein", rustfft_amd.ALGO_BLUESTEIN)] + ([("rader", rustfft_amd.ALGO_RADER)] if args.rader else []) + ([("mixed", rustfft_amd.ALGO_MIXED_RADIX)] if args.mixed else [])
         for name, algo in arms:
             try:
                 fft = planner.plan_fft_with(n, 0, algorithm=algo)
@@ -55,6 +56,8 @@ def main():
             ms = sorted(ts)[1]
             out[name] = {"TBps": round(batch * 2 * n * esz / ms / 1e9, 3), "rel_l2": err, "plan": fft.describe()[:60]}
         out["auto_over_bluestein"] = round(out["auto"]["TBps"] / out["bluestein"]["TBps"], 2)
+        if args.mixed and "TBps" in out.get("mixed", {}):
+            out["mixed_over_bluestein"] = round(out["mixed"]["TBps"] / out["bluestein"]["TBps"], 2)
         if args.rader and "TBps" in out.get("rader", {}):
             out["rader_over_bluestein"] = round(out["rader"]["TBps"] / out["bluestein"]["TBps"], 2)
         print(json.dumps(out), flush=True)
