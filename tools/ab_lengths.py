@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--sizes", default="")
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--gib", type=float, default=0.5)
+    ap.add_argument("--all", action="store_true", help="time a length even when both builds describe the same plan (a changed kernel body keeps its name)")
     args = ap.parse_args()
     dt, tdt, esz = (np.complex64, torch.complex64, 8) if args.dtype == "f32" else (np.complex128, torch.complex128, 16)
     pl = [rustfft_amd.FftPlannerHip(dt, lib=_native.load(os.path.join(ROOT, "rustfft_amd", "lib", p))) for p in (args.a, args.b)]
@@ -51,7 +52,7 @@ def main():
         batch = x.numel() // n
         buf = x[: batch * n]
         ffts = [p.plan_fft_forward(n) for p in pl]
-        if ffts[0].describe() == ffts[1].describe():
+        if ffts[0].describe() == ffts[1].describe() and not args.all:
             continue
         for f in ffts:
             f.process(buf)

@@ -1,10 +1,15 @@
 mkdir -p gpurun_out/r3
-python -m pytest tests -m gpu -x -q 2>&1 | tail -5 | tee gpurun_out/r3/pytest_gpu_k2r.log
-python tools/algo_compare.py --mixed --sizes 1517,3599,4087,8384,8633,10403,10763,65231,158381 > gpurun_out/r3/prime_tiles_ab_f32.jsonl 2>gpurun_out/r3/prime_tiles_ab_f32.err
-python tools/algo_compare.py --mixed --dtype f64 --sizes 1517,8633,10403,65231 > gpurun_out/r3/prime_tiles_ab_f64.jsonl 2>/dev/null
+python tools/ab_lengths.py --all --a libmi355fft.so --b libmi355fft_exp.so --sizes 47,59,83,107,167,179,227,263,347,383,467,503,587,719,839,887,983,1019,1187,1283,1367,1439,1523,1619,1823,1907,2027,2063,2207,2459,2579,2819,2903,2999,3119,3203,3467,3623,3803,3947,4079,4093 > gpurun_out/r3/ab_bluestein_unpredicated_f32.jsonl 2>gpurun_out/r3/ab_bs.err
+python tools/ab_lengths.py --all --dtype f64 --a libmi355fft.so --b libmi355fft_exp.so --sizes 59,167,263,503,719,1019,1283,1523,2027,2579,3119,4079 > gpurun_out/r3/ab_bluestein_unpredicated_f64.jsonl 2>/dev/null
+python tools/ab_lengths.py --a libmi355fft.so --b libmi355fft_k2gt.so --sizes 4200,5000,6561,10000,15625,20449,44100,45056,65000,100000,177147,362880,500000,1000000,1536000,3000000 > gpurun_out/r3/ab_k2g_twl_f32.jsonl 2>/dev/null
+python tools/ab_lengths.py --dtype f64 --a libmi355fft.so --b libmi355fft_k2gt.so --sizes 5000,10000,20449,44100,100000,362880,1000000 > gpurun_out/r3/ab_k2g_twl_f64.jsonl 2>/dev/null
 python3 - <<'PY'
-import json
-for fn in ('gpurun_out/r3/prime_tiles_ab_f32.jsonl','gpurun_out/r3/prime_tiles_ab_f64.jsonl'):
-    for l in open(fn):
-        d=json.loads(l); print(d['n'], d['dtype'], {k:(d[k].get('TBps'), d[k].get('plan','')[:44], '%.1e'%d[k].get('rel_l2',0)) for k in ('auto','bluestein','mixed') if k in d})
+import json,statistics
+for fn in ('ab_bluestein_unpredicated_f32','ab_bluestein_unpredicated_f64','ab_k2g_twl_f32','ab_k2g_twl_f64'):
+    rows=[json.loads(l) for l in open('gpurun_out/r3/%s.jsonl'%fn) if l.startswith('{')]
+    if not rows: print(fn,'EMPTY'); continue
+    r=[x['b_over_a'] for x in rows]
+    print(fn, 'n=%d median %.3f min %.3f max %.3f'%(len(r), statistics.median(r), min(r), max(r)))
+    print('   ', ' '.join('%d:%.2f(%.2f)'%(x['n'],x['b_over_a'],x['b_TBps']) for x in rows))
 PY
+tail -3 gpurun_out/r3/ab_bs.err
