@@ -50,6 +50,7 @@ struct PassDesc {
 struct Workspace {
     void* ptr = nullptr;
     size_t bytes = 0;
+    bool placed = false;  // the placement tournament (plan.cpp place_workspace) has run for this allocation
 };
 
 // Per-(plan, stream) execution slot.  `launch_mutex` is held for the WHOLE enqueue sequence of a multi-pass call
