@@ -301,7 +301,28 @@ MI_HD void k2g_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     constexpr int SEGB = F * (int)sizeof(cx<T>), XP = SEGB >= 512 ? 0 : SEGB >= 256 ? 1 : SEGB >= 128 ? 2 : 3;
     long long g;
     unsigned b0;
-    if constexpr (XP > 0 && FUSE == 0) {
+    if constexpr (FUSE == 4 || FUSE == 6) {
+        // The gather / scatter passes of the multi-kernel Rader touch a caller's row (<= 8 (p - 1) bytes) at random 8- or 16-byte
+        // granularity.  Workgroup b runs on XCD b % 8 and every XCD has its own L2: with the plain order the tiles of ONE row are
+        // spread over all eight, so each L2 fetches the whole row for its gathers (8x the reads) and evicts partially written
+        // lines of the scattered output (up to 16x the writes).  Here all tiles of transform g run on XCD g % 8: one L2 fetches the
+        // row once and merges the scattered stores into full lines before they leave.  (Complete groups of eight transforms; the
+        // last batch % 8 transforms keep the plain order.)
+        const unsigned tpf = (unsigned)p.tiles_per_fft, full = ((unsigned)p.batch >> 3) << 3;
+        const unsigned long long nfull = (unsigned long long)full * tpf;
+        unsigned gi, tile;
+        if ((unsigned long long)block < nfull) {
+            const unsigned blk = (unsigned)block, x = blk & 7u, i = blk >> 3;
+            gi = (i / tpf) * 8u + x;
+            tile = i % tpf;
+        } else {
+            const unsigned r = (unsigned)((unsigned long long)block - nfull);
+            gi = full + r / tpf;
+            tile = r % tpf;
+        }
+        g = (long long)gi;
+        b0 = tile * (unsigned)F;
+    } else if constexpr (XP > 0 && FUSE == 0) {
         if (p.xq > 0 && (block >> 6) < (long long)p.xfull) {
             const int r = (int)(block & 63), x = r & 7, i = r >> 3;
             const int t = ((i >> XP) << (XP + 3)) | (x << XP) | (i & ((1 << XP) - 1));

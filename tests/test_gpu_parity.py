@@ -696,7 +696,8 @@ def test_large_primes_vs_oracle(planners, oracle, dtype):
             # inner transforms of length p - 1) instead of the fused Bluestein over M >= 2p - 1
             assert fft.describe().startswith("rader_large(p-1=%d fused: k2gfirst_gather<" % (p - 1)) and "k2glast_scatter<" in fft.describe(), fft.describe()
             check_fft_algorithm(fft, p, d, reference=oracle.plan(dtype, p, d), n=2)
-            x = zero_mean_signal(p * 3, dtype, seed=p)
+            # 19 rows: two complete groups of eight transforms (tiles of transform g on XCD g % 8 in the gather / scatter passes) + 3
+            x = zero_mean_signal(p * 19, dtype, seed=p)
             y = x.copy()
             fft.process(y)
             assert rel_l2(y, numpy_fft(x, p, d == 1)) < REL[np.dtype(dtype)], (p, d, fft.describe())

@@ -305,6 +305,14 @@ def test_large_prime_rader(emu_planner, oracle, dtype):
             assert "k2glast_rmul<" in fft.describe() and "k2glast_scatter<" in fft.describe(), fft.describe()
             check_fft_algorithm(fft, p, d, reference=oracle.plan(dtype, p, d), n=2 if p < 20000 else 1)
     assert "bluestein" in planner.plan_fft(4481, 0).describe()  # AUTO below the threshold
+    # eleven rows: the gather / scatter passes run the tiles of transform g on XCD g % 8 for complete groups of eight transforms
+    # and in the plain order for the rest -- both index maps in one call
+    for p, algo in ((4481, rustfft_amd.ALGO_RADER), (12289, rustfft_amd.ALGO_AUTO)):
+        x = zero_mean_signal(p * 11, dtype, seed=11)
+        for d in (0, 1):
+            y = x.copy()
+            planner.plan_fft_with(p, d, algorithm=algo).process(y)
+            assert rel_l2(y, numpy_fft(x, p, d == 1)) < (2e-6 if dtype == np.complex64 else 1e-13)
     p = 12289
     x = zero_mean_signal(p * 3, dtype, seed=5)
     for d in (0, 1):
