@@ -418,18 +418,39 @@ MI_HD void k2r_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     const int* MI_RESTRICT perm_out = p.perm2;
     cx<T>* work = (cx<T>*)lds;
     // lanes walk across the tile's columns: thread t holds column t % F and the rows t / F, t / F + TPF, ...
+    // The thread's rows are fetched in batches of eight -- every load of a batch (row element, its two twiddle-table factors, its
+    // slot) is issued before the first one is consumed.  As a run-time loop (load, wait, LDS write, branch) the P / TPF rows of a
+    // thread cost as many DEPENDENT memory round trips, which is what bound these passes at first (1.6 - 2.5 TB/s).
     ex.for_threads([&](int tid, cx<T>*) {
         const unsigned c = (unsigned)tid % (unsigned)F, B = b0 + c, col = B < M ? B : 0;  // masked columns read column 0 (never stored)
-        const unsigned cs = FIRST ? 0u : col % Sg;
-        for (unsigned r = (unsigned)tid / (unsigned)F; r < (unsigned)P; r += (unsigned)S::TPF) {
-            cx<T> x = in[col + r * M];
-            x.im *= sgn_in;
-            if constexpr (!FIRST) {
-                const unsigned e = cs * r;
-                x = x * (tlo[e & (unsigned)lmask] * thi[e >> hshift]);
-            }
-            work[c * PITCH + (r == 0 ? (unsigned)XS : (unsigned)perm_in[r])] = x;
-        }
+        const unsigned cs = FIRST ? 0u : col % Sg, r0 = (unsigned)tid / (unsigned)F;
+        constexpr int NL = (P + S::TPF - 1) / S::TPF, CH = 8;
+        static_for<0, (NL + CH - 1) / CH>([&](auto Q_) {
+            constexpr int q = Q_, nq = (NL - q * CH < CH) ? NL - q * CH : CH;
+            cx<T> xr[nq], wl[nq], wh[nq];
+            unsigned slot[nq];
+            static_for<0, nq>([&](auto I_) {
+                constexpr int i = I_;
+                const unsigned r = r0 + (unsigned)((q * CH + i) * S::TPF), rr = r < (unsigned)P ? r : 0u;
+                xr[i] = in[col + rr * M];
+                slot[i] = (unsigned)perm_in[rr];
+                if constexpr (!FIRST) {
+                    const unsigned e = cs * rr;
+                    wl[i] = tlo[e & (unsigned)lmask];
+                    wh[i] = thi[e >> hshift];
+                }
+            });
+            static_for<0, nq>([&](auto I_) {
+                constexpr int i = I_;
+                const unsigned r = r0 + (unsigned)((q * CH + i) * S::TPF);
+                if (r < (unsigned)P) {
+                    cx<T> x = xr[i];
+                    x.im *= sgn_in;
+                    if constexpr (!FIRST) x = x * (wl[i] * wh[i]);
+                    work[c * PITCH + (r == 0 ? (unsigned)XS : slot[i])] = x;
+                }
+            });
+        });
     });
     ex.barrier();
     auto src1 = [=](int f, int j) -> cx<T> { return work[f * PITCH + j]; };
@@ -662,16 +683,33 @@ MI_HD void rader_body(X& ex, const RaderParams<T>& p, long long block, void* lds
         // target of the output with g^-(j+1) = p - 1: the slot must not be below p (round 2: a race that a rescheduling exposed).
         constexpr int XS = (S::phys(M - 1) + 1 > P) ? S::phys(M - 1) + 1 : P;
         static_assert(XS < PITCH && P <= PITCH, "row pitch must leave a spare slot");
+        // batches of eight elements per thread: all loads of a batch (element, slot) in flight before the first LDS write -- a
+        // run-time loop costs one dependent memory round trip per element (F P / NT of them)
         ex.for_threads([&](int tid, cx<T>*) {
-            for (int t = tid; t < F * P; t += NT) {
-                const int f = t / P, i = t - f * P;
-                cx<T> x = cx<T>{0, 0};
-                if (t < valid) {
-                    x = in[fft0 * P + t];
-                    x.im *= sgn;
-                }
-                work[f * PITCH + (i == 0 ? XS : perm_in[i])] = x;
-            }
+            constexpr int NL = (F * P + NT - 1) / NT, CH = 8;
+            const cx<T>* rowsp = in + fft0 * P;
+            static_for<0, (NL + CH - 1) / CH>([&](auto Q_) {
+                constexpr int q = Q_, nq = (NL - q * CH < CH) ? NL - q * CH : CH;
+                cx<T> xr[nq];
+                int slot[nq];
+                static_for<0, nq>([&](auto I_) {
+                    constexpr int i = I_;
+                    const int t = tid + (q * CH + i) * NT, tc = t < F * P ? t : 0, f = tc / P, e = tc - f * P;
+                    xr[i] = rowsp[t < valid ? t : 0];
+                    const int pj = perm_in[e];  // unconditional (entry 0 of the inverse map is a spare 0): no branch around the load
+                    slot[i] = f * PITCH + (e == 0 ? XS : pj);
+                });
+                static_for<0, nq>([&](auto I_) {
+                    constexpr int i = I_;
+                    const int t = tid + (q * CH + i) * NT;
+                    if (t < F * P) {
+                        cx<T> x = xr[i];
+                        x.im *= sgn;
+                        const bool ok = t < valid;  // rows past the batch: zeros
+                        work[slot[i]] = cx<T>{ok ? x.re : (T)0, ok ? x.im : (T)0};
+                    }
+                });
+            });
         });
         ex.barrier();
         auto src1 = [=](int f, int j) -> cx<T> { return work[f * PITCH + j]; };
