@@ -1,19 +1,11 @@
 mkdir -p gpurun_out/r3
-PR=$(python3 -c "print(','.join(str(p) for p in range(17,1300) if all(p%q for q in range(2,int(p**0.5)+1))))")
-python tools/ab_lengths.py --all --a libmi355fft_prev.so --b libmi355fft.so --sizes $PR > gpurun_out/r3/ab_batched_loads_primes_f32.jsonl 2>/dev/null
-python tools/ab_lengths.py --all --dtype f64 --a libmi355fft_prev.so --b libmi355fft.so --sizes 37,41,53,61,73,97,101,113,127,151,181,193,241,257,281,313,337,401,433,449,521,541,577,601,641,673,769 > gpurun_out/r3/ab_batched_loads_primes_f64.jsonl 2>/dev/null
-python tools/ab_lengths.py --all --a libmi355fft_prev.so --b libmi355fft.so --sizes 8384,8633,10403,10763,65231,158381 > gpurun_out/r3/ab_batched_loads_k2r_f32.jsonl 2>/dev/null
-python tools/ab_lengths.py --all --dtype f64 --a libmi355fft_prev.so --b libmi355fft.so --sizes 8633,10403,65231 > gpurun_out/r3/ab_batched_loads_k2r_f64.jsonl 2>/dev/null
+python tools/ab_lengths.py --all --a libmi355fft.so --b libmi355fft_exp.so --sizes 47,59,83,107,167,179,227,263,347,383,467,503,587,719,839,887,983,1019,1187,1283,1367,1439,1523,1619,1823,1907,2027,2063,2207,2459,2579,2819,2903,2999,3119,3203,3467,3623,3803,3947,4079,4093 > gpurun_out/r3/ab_bluestein_input_batched_f32.jsonl 2>/dev/null
+python tools/ab_lengths.py --all --dtype f64 --a libmi355fft.so --b libmi355fft_exp.so --sizes 59,167,263,503,719,1019,1283,1523,2027,2579,3119,4079 > gpurun_out/r3/ab_bluestein_input_batched_f64.jsonl 2>/dev/null
 python3 - <<'PY'
 import json,statistics
-for fn in ('ab_batched_loads_primes_f32','ab_batched_loads_primes_f64','ab_batched_loads_k2r_f32','ab_batched_loads_k2r_f64'):
+for fn in ('ab_bluestein_input_batched_f32','ab_bluestein_input_batched_f64'):
     rows=[json.loads(l) for l in open('gpurun_out/r3/%s.jsonl'%fn) if l.startswith('{')]
-    if not rows: print(fn,'EMPTY'); continue
-    rad=[x for x in rows if 'rader' in x['plan_b'] or 'k2r' in x['plan_b']]
-    oth=[x for x in rows if x not in rad]
-    for nm,rr in (('rader/k2r',rad),('other',oth)):
-        if not rr: continue
-        r=[x['b_over_a'] for x in rr]
-        print(fn, nm, 'n=%d median %.3f min %.3f max %.3f'%(len(r), statistics.median(r), min(r), max(r)))
-    print('   ', ' '.join('%d:%.2f(%.2f)'%(x['n'],x['b_over_a'],x['b_TBps']) for x in rad[:80]))
+    r=[x['b_over_a'] for x in rows]
+    print(fn, 'n=%d median %.3f min %.3f max %.3f'%(len(r), statistics.median(r), min(r), max(r)))
+    print('   ', ' '.join('%d:%.2f(%.2f)'%(x['n'],x['b_over_a'],x['b_TBps']) for x in rows))
 PY
