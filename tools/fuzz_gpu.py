@@ -32,7 +32,25 @@ def main():
                     break
                 n *= p
             n = max(n, 2)
-        if it % 7 == 0:  # edge neighbourhoods of the planner's thresholds
+        if os.environ.get("FUZZ_ROUND3") == "1":
+            # round-3 plans: composites with prime factors 37 .. 631 (prime tile heights), primes above 8192 with 13-smooth p - 1
+            # (multi-kernel Rader), the small primes served by the side-by-side Rader bodies (batched loads)
+            k2r = [p for p in range(37, 640) if all(p % q for q in range(2, int(p**0.5) + 1))]
+            if it % 3 == 0:
+                n = int(rng.choice(k2r)) * int(rng.choice(k2r + [25, 32, 49, 64, 100, 128, 243, 360, 512, 625]))
+                if n <= 4096 or rng.uniform() < 0.25:
+                    n *= int(rng.choice([27, 32, 35, 64, 100]))
+            elif it % 3 == 1:
+                while True:
+                    n = 1
+                    while n < 8192:
+                        n *= int(rng.choice([2, 2, 2, 3, 3, 5, 7, 11, 13]))
+                    n += 1
+                    if n < 1_500_000 and all(n % q for q in range(2, int(n**0.5) + 1)):
+                        break
+            else:
+                n = int(rng.choice([p for p in range(17, 1300) if all(p % q for q in range(2, int(p**0.5) + 1))]))
+        elif it % 7 == 0:  # edge neighbourhoods of the planner's thresholds
             n = int(rng.choice([4096, 4097, 8191, 8193, 16383, 16384, 16385, 32768, 32769, 2 * 16384 - 1, 409600, 409601])) + int(rng.integers(0, 2))
         dt = np.complex64 if rng.integers(0, 2) else np.complex128
         d = int(rng.integers(0, 2))
