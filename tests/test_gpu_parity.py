@@ -471,7 +471,7 @@ def test_single_kernel_above_4096(planners, oracle, dtype):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sizes = [8192, 16384] + ([32768] if dtype == np.complex64 else [])
     for f in glob.glob(os.path.join(root, "rustfft_amd", "csrc", "kernels_smooth2_%s_*.hip" % tag)):
-        sizes += [int(m) for m in re.findall(r"MI_K1\(\w+, \d+, 1, true, (\d+),", open(f).read())]
+        sizes += [int(m) for m in re.findall(r'MI_K1X?\(\w+, \d+, 1, true, (?:\d+, "t1", )?(\d+),', open(f).read())]
     assert len(sizes) > 100
     for n in sorted(sizes):
         d = n % 2

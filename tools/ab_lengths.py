@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--b", required=True)
     ap.add_argument("--set", default="smooth13", choices=["smooth13", "primes"])
     ap.add_argument("--sizes", default="")
+    ap.add_argument("--sizes-file", default="", help="file with comma- or whitespace-separated lengths")
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--gib", type=float, default=0.5)
     ap.add_argument("--all", action="store_true", help="time a length even when both builds describe the same plan (a changed kernel body keeps its name)")
@@ -39,7 +40,9 @@ def main():
                 v //= q
         return v == 1
 
-    if args.sizes:
+    if args.sizes_file:
+        sizes = [int(v) for v in open(args.sizes_file).read().replace(",", " ").split()]
+    elif args.sizes:
         sizes = [int(s) for s in args.sizes.split(",")]
     elif args.set == "smooth13":
         sizes = [v for v in range(3, 4097) if smooth(v) and (v & (v - 1))]

@@ -14,6 +14,27 @@ import math
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# Sub-pass 1's twiddle table staged in LDS (engine.h TWL; kernel name suffix "t1") -- a per-length measured choice, round 3:
+# one-process interleaved A/B of EVERY compiled length, shipped build vs a build with the table staged everywhere
+# (profiles/r3/ab_smooth_twl1_all_{f32,f64}.jsonl): f32 median +11 % (1162 of 1251 lengths win by > 2 %, 50 do not win and are
+# listed as exceptions), f64 median -1 % (129 lengths win by >= 4 % and are listed).
+try:
+    import json as _json
+
+    _TWL = _json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "smooth_twl_choice.json")))
+except OSError:
+    _TWL = {"f32_exclude": [], "f64_include": []}
+_TWL32_EXCLUDE, _TWL64_INCLUDE = set(_TWL["f32_exclude"]), set(_TWL["f64_include"])
+
+
+def k1_line(ty, prec, f, split, n, tpf, rad):
+    staged = len(rad) >= 2 and ((prec == 32 and n not in _TWL32_EXCLUDE) or (prec == 64 and n in _TWL64_INCLUDE))
+    args = f"{n}, {tpf}, {', '.join(map(str, rad))}"
+    if staged:
+        return f'    MI_K1X({ty}, {prec}, {f}, {split}, 1024, "t1", {args});'
+    return f"    MI_K1({ty}, {prec}, {f}, {split}, {args});"
+
 RADICES = [16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2]
 EMAX = 16
 NFILES = 8
@@ -175,7 +196,7 @@ def main_big():
             lines = []
             for n in sizes[ci::nfiles]:
                 rad, tpf = big_schedule(n, emaxes) if n <= 16384 else big_schedule32(n)
-                lines.append(f"    MI_K1({ty}, {prec}, 1, true, {n}, {tpf}, {', '.join(map(str, rad))});")
+                lines.append(k1_line(ty, prec, 1, "true", n, tpf, rad))
             path = os.path.join(ROOT, "rustfft_amd", "csrc", f"kernels_smooth2_{tag}_{ci}.hip")
             with open(path, "w") as fh:
                 fh.write(f"// GENERATED by tools/gen_smooth_kernels.py — do not edit.  Single-kernel schedules (split exchange) for the 7-smooth\n"
@@ -216,7 +237,7 @@ def main_primes(limits=(("f32", "float", 32, 8, 4096, 14), ("f64", "double", 64,
                 # 113 of 389 changed f32 lengths, 36 of 89 f64; the median over all of them is 0.99 / 1.02, so the rule stays)
                 if ROWS31_TARGET == 256 and str(n) in _CHOICES.get("rows31", {}).get(tag, {}):
                     f = _CHOICES["rows31"][tag][str(n)]
-                lines.append(f"    MI_K1({ty}, {prec}, {f}, false, {n}, {tpf}, {', '.join(map(str, rad))});")
+                lines.append(k1_line(ty, prec, f, "false", n, tpf, rad))
             path = os.path.join(ROOT, "rustfft_amd", "csrc", f"kernels_smooth3_{tag}_{ci}.hip")
             with open(path, "w") as fh:
                 fh.write(f"// GENERATED by tools/gen_smooth_kernels.py — do not edit.  Compiled K1 schedules for the lengths <= {limit} with a prime\n"
@@ -239,7 +260,7 @@ def main():
                 if SCHED_ALT or str(n) in SCHED_CHOICE[tag]:
                     rad, tpf = schedule_small_radix(n)
                 f = rows_per_wg(n, tpf, esz)
-                lines.append(f"    MI_K1({ty}, {prec}, {f}, false, {n}, {tpf}, {', '.join(map(str, rad))});")
+                lines.append(k1_line(ty, prec, f, "false", n, tpf, rad))
             path = os.path.join(ROOT, "rustfft_amd", "csrc", f"kernels_smooth_{tag}_{ci}.hip")
             with open(path, "w") as fh:
                 fh.write(f"// GENERATED by tools/gen_smooth_kernels.py — do not edit.  Compiled K1 schedules for the 13-smooth lengths in\n"
