@@ -406,7 +406,7 @@ template <class T, class S, int F, bool SPLIT, int PM = 1, int TWL = 0> constexp
 // src(f, i) -> cx<T>: input element i of sequence f;   dst(f, i, value): output element i.
 // ABL (compile-time, tuning builds only): bit 2 skips the arithmetic, bit 3 skips the LDS exchange — ablation probes
 // that keep the HBM access pattern; production instantiations use ABL = 0.
-template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, int PM, int ABL, int P, int TWREG = -1, bool TWSTAGE = false, int TWL = 0, class X, class SRC, class DST>
+template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, int PM, int ABL, int P, int TWREG = -1, bool TWSTAGE = false, int TWL = 0, int TWLOFF = 0, class X, class SRC, class DST>
 MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& src, DST& dst) {
     constexpr int R = S::R[P], NB = S::nb(P), ST = S::stride(P), BPT = S::bpt(P);
     constexpr Map MP = pass_map<S, P, MIN, MOUT>();
@@ -414,7 +414,7 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
     // this sub-pass's factors: the global table, or its LDS copy (compute_pass adds S::tw_offset(P) to whatever it is given)
     const cx<T>* twp = tw;
     if constexpr (((TWL >> P) & 1) != 0)
-        twp = (const cx<T>*)((char*)lds_raw + align16(lds_bytes<T, S, F, SPLIT, PM>())) - S::tw_offset(twl_first<S>(TWL));
+        twp = (const cx<T>*)((char*)lds_raw + align16(lds_bytes<T, S, F, SPLIT, PM>()) + TWLOFF) - S::tw_offset(twl_first<S>(TWL));
     // arithmetic of pass P, then either the final store or the scatter half of the exchange
     ex.for_threads([&](int tid, cx<T>* v) {
         int f, u;
@@ -446,7 +446,7 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
         }
     });
     if constexpr (!LAST && (ABL & 8) != 0) {
-        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, P + 1, TWREG, TWSTAGE, TWL>(ex, lds_raw, tw, src, dst);
+        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, P + 1, TWREG, TWSTAGE, TWL, TWLOFF>(ex, lds_raw, tw, src, dst);
     } else if constexpr (!LAST) {
         constexpr Map MQ = pass_map<S, P + 1, MIN, MOUT>();
         ex.barrier();
@@ -481,7 +481,7 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
             });
             ex.barrier();
         }
-        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, P + 1, TWREG, TWSTAGE, TWL>(ex, lds_raw, tw, src, dst);
+        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, P + 1, TWREG, TWSTAGE, TWL, TWLOFF>(ex, lds_raw, tw, src, dst);
     }
 }
 
@@ -507,14 +507,17 @@ template <class SRC> struct src_loads_all<SRC, std::enable_if_t<SRC::kLoadsAll>>
 
 // SRC_IN_LDS: `src` reads the same LDS buffer the exchanges use (Rader/Bluestein second transform), so a
 // barrier separates the loads from the first scatter.
-template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, bool SRC_IN_LDS = false, int PM = 1, int ABL = 0, int TWREG = -1, bool TWSTAGE = false, int TWL = 0, class X, class SRC, class DST>
+// TWLOFF: byte offset of this transform's staged tables behind the exchange buffer (bodies that run two transforms through one
+// buffer -- Bluestein -- give each its own region, so the second transform's staging cannot overwrite a table a slow wave of the
+// first is still reading)
+template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, bool SRC_IN_LDS = false, int PM = 1, int ABL = 0, int TWREG = -1, bool TWSTAGE = false, int TWL = 0, int TWLOFF = 0, class X, class SRC, class DST>
 MI_HD void wg_fft(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC src, DST dst) {
     static_assert(S::valid(), "radices must multiply to N");
     static_assert(MIN != MAP_FFP || (pair_fusable<S>() && !SRC_IN_LDS && TWREG < 0 && sizeof(T) == 4), "the paired map is the pair-fused path");
     static_assert(TWL == 0 || (twl_valid<S>(TWL) && !SRC_IN_LDS && TWREG < 0 && MIN != MAP_FFP && S::NP >= 2), "staged tables: plain transforms whose first exchange publishes the copy");
     constexpr int R0 = S::R[0], NB0 = S::nb(0), BPT0 = S::bpt(0);
     constexpr int TWN = twl_total<S>(TWL), NT = F * S::TPF, TWPT = (TWN + NT - 1) / NT, TWSRC = S::tw_offset(twl_first<S>(TWL));
-    cx<T>* twl = (cx<T>*)((char*)lds_raw + align16(lds_bytes<T, S, F, SPLIT, PM>()));
+    cx<T>* twl = (cx<T>*)((char*)lds_raw + align16(lds_bytes<T, S, F, SPLIT, PM>()) + TWLOFF);
     // inputs of sub-pass 0 straight from the source
     ex.for_threads([&](int tid, cx<T>* v) {
         int f, u;
@@ -594,9 +597,9 @@ MI_HD void wg_fft(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC src, DS
             });
             ex.barrier();
         }
-        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, 2, TWREG, TWSTAGE, TWL>(ex, lds_raw, tw, src, dst);
+        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, 2, TWREG, TWSTAGE, TWL, TWLOFF>(ex, lds_raw, tw, src, dst);
     } else {
-        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, 0, TWREG, TWSTAGE, TWL>(ex, lds_raw, tw, src, dst);
+        wg_fft_stage<T, S, F, MIN, MOUT, SPLIT, PM, ABL, 0, TWREG, TWSTAGE, TWL, TWLOFF>(ex, lds_raw, tw, src, dst);
     }
 }
 

@@ -528,7 +528,17 @@ template <class T, class S2> struct BluesteinRegSrc {
 // SPLIT (real / imaginary planes exchanged one after the other): with no staged spectrum, a padded length up to 32768 (f64:
 // 16384) fits one workgroup's LDS, so lengths up to 16384 run in ONE kernel at 2 n elements of traffic (round 1: two
 // whole-row kernels through an HBM workspace, 2 M + 2 n elements).
-template <class T, class S, int F, bool SPLIT = false, class X>
+// TW1 (a per-inner-length measured option): sub-pass 1's twiddle table of BOTH transforms staged in LDS (engine.h TWL), each in
+// its own region behind the exchange buffer; schedules with at least three sub-passes only (with two, sub-pass 1 is the last one
+// and its table would be the big one)
+template <class S> constexpr bool bluestein_tw1_ok() { return S::NP >= 3; }
+template <class T, class S, int F, bool SPLIT, bool TW1> constexpr size_t bluestein_lds_bytes() {
+    using S2 = typename reversed_sched<S>::type;
+    const size_t ex = (size_t)F * (S::pitch() > S2::pitch() ? S::pitch() : S2::pitch()) * (SPLIT ? sizeof(T) : sizeof(cx<T>));
+    if (!(TW1 && bluestein_tw1_ok<S>())) return ex;
+    return align16(ex) + align16((size_t)tw_pass_entries<S>(1) * sizeof(cx<T>)) + (size_t)tw_pass_entries<S2>(1) * sizeof(cx<T>);
+}
+template <class T, class S, int F, bool SPLIT = false, bool TW1 = false, class X>
 MI_HD void bluestein_body(X& ex, const BluesteinParams<T>& p, long long block, void* lds) {
     using S2 = typename reversed_sched<S>::type;
     static_assert(S2::R[0] == S::R[S::NP - 1] && S2::nb(0) == S::nb(S::NP - 1) && S2::bpt(0) == S::bpt(S::NP - 1), "register hand-over");
@@ -548,7 +558,12 @@ MI_HD void bluestein_body(X& ex, const BluesteinParams<T>& p, long long block, v
         }
         return cx<T>{0, 0};
     };
-    wg_fft<T, S, F, MAP_EF, MAP_EF, SPLIT>(ex, lds, p.tw, elem_src(src1), KeepInRegs{});
+    // both transforms share one exchange buffer of max(pitch) entries per row; the staged tables sit behind it
+    constexpr bool STG = TW1 && bluestein_tw1_ok<S>();
+    constexpr size_t EXB = (size_t)F * (S::pitch() > S2::pitch() ? S::pitch() : S2::pitch()) * (SPLIT ? sizeof(T) : sizeof(cx<T>));
+    constexpr int OFF1 = STG ? (int)(align16(EXB) - align16(lds_bytes<T, S, F, SPLIT>())) : 0;
+    constexpr int OFF2 = STG ? (int)(align16(EXB) + align16((size_t)tw_pass_entries<S>(1) * sizeof(cx<T>)) - align16(lds_bytes<T, S2, F, SPLIT>())) : 0;
+    wg_fft<T, S, F, MAP_EF, MAP_EF, SPLIT, false, 1, 0, -1, false, (STG ? 2 : 0), OFF1>(ex, lds, p.tw, elem_src(src1), KeepInRegs{});
     // (the engine's barrier after the last gather of the first transform already orders it before the second one's scatters)
     auto dst2 = [=](int f, int j, cx<T> v) {
         if (f < rows && j < n) {
@@ -557,7 +572,7 @@ MI_HD void bluestein_body(X& ex, const BluesteinParams<T>& p, long long block, v
             out[(unsigned)(f * n + j)] = y;
         }
     };
-    wg_fft<T, S2, F, MAP_EF, MAP_EF, SPLIT>(ex, lds, p.tw2, BluesteinRegSrc<T, S2>{p.bf}, dst2);
+    wg_fft<T, S2, F, MAP_EF, MAP_EF, SPLIT, false, 1, 0, -1, false, (STG ? 2 : 0), OFF2>(ex, lds, p.tw2, BluesteinRegSrc<T, S2>{p.bf}, dst2);
 }
 
 // ---- run-time scheduled batched transform (13-smooth lengths) ------------------------------------------------

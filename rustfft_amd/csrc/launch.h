@@ -136,11 +136,11 @@ template <class T, class S, int F, bool FIRST, bool SPLIT, int ABL = 0> KernelEn
     };
     return e;
 }
-template <class T, class S, int F, bool SPLIT = false>
+template <class T, class S, int F, bool SPLIT = false, bool TW1 = false>
 __global__ __launch_bounds__(F* S::TPF) void bluestein_kernel(BluesteinParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DevExec<T, regs_needed<S, false>()> ex;
-    bluestein_body<T, S, F, SPLIT>(ex, p, (long long)blockIdx.x, smem);
+    bluestein_body<T, S, F, SPLIT, TW1>(ex, p, (long long)blockIdx.x, smem);
 }
 template <class T, class S, int F, int MODE>
 // MODE 2: rows loop with next-row prefetch (>= 3 waves per SIMD in f32); MODE 3: without the prefetch; MODE 4: as MODE 2 for the
@@ -173,16 +173,15 @@ template <class T> KernelEntry make_pointwise(int prec) {
     e.prepare = []() -> int { return 0; };
     return e;
 }
-template <class T, class S, int F, bool SPLIT = false> constexpr size_t bluestein_lds() {
-    using S2 = typename reversed_sched<S>::type;  // the second transform runs the reversed schedule (kernels.h bluestein_body)
-    return (size_t)F * (S::pitch() > S2::pitch() ? S::pitch() : S2::pitch()) * (SPLIT ? sizeof(T) : sizeof(cx<T>));
+template <class T, class S, int F, bool SPLIT = false, bool TW1 = false> constexpr size_t bluestein_lds() {
+    return bluestein_lds_bytes<T, S, F, SPLIT, TW1>();  // exchange buffer of both schedules (+ the staged tables)
 }
 template <class T, class S, int F, int MODE> constexpr size_t rader_lds() {
     if (MODE >= 2) return (size_t)RaderRows<S>::SLOTS * sizeof(cx<T>);  // one row at a time
     return (size_t)F * (S::pitch() + (MODE >= 1 ? 0 : S::N + 1)) * sizeof(cx<T>);
 }
 
-template <class T, class S, int F, bool SPLIT = false> KernelEntry make_bluestein(int prec, const char* name) {
+template <class T, class S, int F, bool SPLIT = false, bool TW1 = false> KernelEntry make_bluestein(int prec, const char* name) {
     KernelEntry e{};
     e.kind = KIND_BLUESTEIN;
     e.prec = prec;
@@ -190,16 +189,16 @@ template <class T, class S, int F, bool SPLIT = false> KernelEntry make_bluestei
     e.f = F;
     fill_sched<S>(e);
     e.threads = F * S::TPF;
-    e.lds_bytes = bluestein_lds<T, S, F, SPLIT>();
+    e.lds_bytes = bluestein_lds<T, S, F, SPLIT, TW1>();
     e.name = name;
     e.launch = [](const void* params, long long grid, void* stream) {
         void* args[] = {const_cast<void*>(params)};
-        (void)hipLaunchKernel((const void*)bluestein_kernel<T, S, F, SPLIT>, dim3((unsigned)grid), dim3(F * S::TPF), args,
-                              bluestein_lds<T, S, F, SPLIT>(), (hipStream_t)stream);
+        (void)hipLaunchKernel((const void*)bluestein_kernel<T, S, F, SPLIT, TW1>, dim3((unsigned)grid), dim3(F * S::TPF), args,
+                              bluestein_lds<T, S, F, SPLIT, TW1>(), (hipStream_t)stream);
     };
     e.prepare = []() -> int {
-        return (int)hipFuncSetAttribute((const void*)bluestein_kernel<T, S, F, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)bluestein_lds<T, S, F, SPLIT>());
+        return (int)hipFuncSetAttribute((const void*)bluestein_kernel<T, S, F, SPLIT, TW1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)bluestein_lds<T, S, F, SPLIT, TW1>());
     };
     return e;
 }
@@ -451,15 +450,14 @@ template <class T> KernelEntry make_pointwise(int prec) {
     e.prepare = []() -> int { return 0; };
     return e;
 }
-template <class T, class S, int F, bool SPLIT = false> constexpr size_t bluestein_lds() {
-    using S2 = typename reversed_sched<S>::type;  // the second transform runs the reversed schedule (kernels.h bluestein_body)
-    return (size_t)F * (S::pitch() > S2::pitch() ? S::pitch() : S2::pitch()) * (SPLIT ? sizeof(T) : sizeof(cx<T>));
+template <class T, class S, int F, bool SPLIT = false, bool TW1 = false> constexpr size_t bluestein_lds() {
+    return bluestein_lds_bytes<T, S, F, SPLIT, TW1>();  // exchange buffer of both schedules (+ the staged tables)
 }
 template <class T, class S, int F, int MODE> constexpr size_t rader_lds() {
     if (MODE >= 2) return (size_t)RaderRows<S>::SLOTS * sizeof(cx<T>);  // one row at a time
     return (size_t)F * (S::pitch() + (MODE >= 1 ? 0 : S::N + 1)) * sizeof(cx<T>);
 }
-template <class T, class S, int F, bool SPLIT = false> KernelEntry make_bluestein(int prec, const char* name) {
+template <class T, class S, int F, bool SPLIT = false, bool TW1 = false> KernelEntry make_bluestein(int prec, const char* name) {
     KernelEntry e{};
     e.kind = KIND_BLUESTEIN;
     e.prec = prec;
@@ -467,13 +465,13 @@ template <class T, class S, int F, bool SPLIT = false> KernelEntry make_bluestei
     e.f = F;
     fill_sched<S>(e);
     e.threads = F * S::TPF;
-    e.lds_bytes = bluestein_lds<T, S, F, SPLIT>();
+    e.lds_bytes = bluestein_lds<T, S, F, SPLIT, TW1>();
     e.name = name;
     e.launch = [](const void* params, long long grid, void*) {
-        std::vector<char> lds(bluestein_lds<T, S, F, SPLIT>() + 64, (char)0x5a);
+        std::vector<char> lds(bluestein_lds<T, S, F, SPLIT, TW1>() + 64, (char)0x5a);
         for (long long b = 0; b < grid; ++b) {
             HostExec<T, regs_needed<S, false>()> ex(F * S::TPF);
-            bluestein_body<T, S, F, SPLIT>(ex, *(const BluesteinParams<T>*)params, b, lds.data());
+            bluestein_body<T, S, F, SPLIT, TW1>(ex, *(const BluesteinParams<T>*)params, b, lds.data());
         }
     };
     e.prepare = []() -> int { return 0; };
@@ -672,9 +670,28 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
     reg.push_back(make_k2r<T, Sched<__VA_ARGS__>, F, true>(PREC, "k2rfirst<" #__VA_ARGS__ ">xF" #F)); \
     reg.push_back(make_k2r<T, Sched<__VA_ARGS__>, F, false>(PREC, "k2rlater<" #__VA_ARGS__ ">xF" #F))
 // Bluestein bodies take the linear exchange layout (SchedL): 164 -> 124 VGPRs for the power-of-two inner lengths
-#define MI_BS(T, PREC, F, ...) reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F))
+// Sub-pass 1's twiddle table of both transforms staged in LDS (kernels.h bluestein_body TW1, name suffix "t1"): a per-inner-length
+// measured choice (round 3, shipped build vs a build with the tables staged in every body, 151 / 149 lengths over all inner
+// lengths, one process: profiles/r3/ab_bluestein_tw1_{f32,f64}.jsonl) -- the inner lengths whose median gain is >= 4 %:
+// f32 +6 ... 25 % (256 ... 1536: +7 ... 25 %), f64 +5 ... 8 %; the others are within +-3 % or lose (16384: -15 %, f64 3072: -14 %).
+template <class T, class S> constexpr bool bs_tw1() {
+#if defined(MI355_BS_TW1)  // A/B builds: every body
+    return bluestein_tw1_ok<S>();
+#else
+    constexpr int M = S::N;
+    if (sizeof(T) == 4)
+        return bluestein_tw1_ok<S>() && (M == 256 || M == 320 || M == 384 || M == 512 || M == 640 || M == 1024 || M == 1280 || M == 1536 || M == 2560 || M == 4096 ||
+                                         M == 5120 || M == 7168 || M == 12288);
+    return bluestein_tw1_ok<S>() && (M == 896 || M == 1024 || M == 1536 || M == 2560 || M == 4096);
+#endif
+}
+#define MI_BS(T, PREC, F, ...)                                                                                  \
+    reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F, false, bs_tw1<T, SchedL<__VA_ARGS__>>()>(           \
+        PREC, bs_tw1<T, SchedL<__VA_ARGS__>>() ? "bluestein<" #__VA_ARGS__ ">xF" #F "t1" : "bluestein<" #__VA_ARGS__ ">xF" #F))
 // one-kernel Bluestein through the split exchange (padded lengths above 8192: one workgroup per row)
-#define MI_BSS(T, PREC, F, ...) reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F, true>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F "s"))
+#define MI_BSS(T, PREC, F, ...)                                                                                \
+    reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F, true, bs_tw1<T, SchedL<__VA_ARGS__>>()>(            \
+        PREC, bs_tw1<T, SchedL<__VA_ARGS__>>() ? "bluestein<" #__VA_ARGS__ ">xF" #F "st1" : "bluestein<" #__VA_ARGS__ ">xF" #F "s"))
 #if defined(MI355_TUNING)
 #define MI_BSV(V, T, PREC, F, ...)                                                                    \
     reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F "v" #V)); \
