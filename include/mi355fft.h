@@ -82,8 +82,44 @@ int mi355fft_plan_destroy(mi355fft_plan* plan);
  *                rader: len - 1 entries, built with the smallest primitive root (src/math_utils.rs:3-20).
  *                bluestein: len chirp entries and inner_len multiplier entries; inner_len must be an inner length this
  *                build has a kernel for (query: mi355fft_bluestein_inner_len), else MI355FFT_ERR_INVALID_ARG.
- * struct_size = sizeof(mi355fft_plan_options) (forward compatibility).  NULL options == mi355fft_plan_create. */
+ *   recipe / recipe_nodes
+ *                the host planner's whole Recipe TREE (src/plan.rs:134-188), flattened: node 0 is the root, a child's index
+ *                is larger than its parent's.  The library checks it the way the reference's constructors assert
+ *                (root len == len; MixedRadix / GoodThomas: left.len * right.len == len, mixed_radix.rs:53-62; Raders:
+ *                inner.len == len - 1, raders_algorithm.rs:68-78; Bluesteins: inner.len >= 2 len - 1,
+ *                bluesteins_algorithm.rs:55-61 -- else MI355FFT_ERR_INVALID_ARG) and takes from it
+ *                  - the top-level family (as `algorithm`, which it overrides when `algorithm` is AUTO),
+ *                  - for a MixedRadix / GoodThomas root that does not fit one workgroup: the six-step SPLIT -- the
+ *                    leaves of the MixedRadix / GoodThomas sub-tree, right (height: the transforms that run first,
+ *                    mixed_radix.rs:128-158) before left (width), become the column-tile pass heights when every one of
+ *                    them has a compiled tile,
+ *                  - for a Bluesteins root: the inner length, when a kernel of that inner length exists.
+ *                Everything below that (which butterflies, Radix4 vs RadixN inside a tile) encodes CPU cache behaviour
+ *                and stays the GPU planner's choice; a split the build cannot realise falls back to the GPU planner's own
+ *                within the same family.  mi355fft_plan_recipe_status tells which happened.
+ * struct_size = sizeof(mi355fft_plan_options) as the CALLER was compiled (forward compatibility: fields beyond it are
+ * taken as zero, so a binding written against an earlier header keeps working).  NULL options == mi355fft_plan_create. */
 enum { MI355FFT_ALGO_AUTO = 0, MI355FFT_ALGO_RADER = 1, MI355FFT_ALGO_BLUESTEIN = 2, MI355FFT_ALGO_MIXED_RADIX = 3 };
+/* Recipe kinds, one per variant of `enum Recipe` (src/plan.rs:134-188); BUTTERFLY stands for Butterfly2 .. Butterfly32
+ * (the size is the node's len). */
+enum {
+    MI355FFT_RECIPE_DFT = 0,
+    MI355FFT_RECIPE_MIXED_RADIX = 1,
+    MI355FFT_RECIPE_GOOD_THOMAS = 2,
+    MI355FFT_RECIPE_MIXED_RADIX_SMALL = 3,
+    MI355FFT_RECIPE_GOOD_THOMAS_SMALL = 4,
+    MI355FFT_RECIPE_RADERS = 5,
+    MI355FFT_RECIPE_BLUESTEINS = 6,
+    MI355FFT_RECIPE_RADIXN = 7,
+    MI355FFT_RECIPE_RADIX4 = 8,
+    MI355FFT_RECIPE_BUTTERFLY = 9
+};
+typedef struct mi355fft_recipe_node {
+    int kind;   /* MI355FFT_RECIPE_*                                                              */
+    int left;   /* node index of left_fft / inner_fft / base_fft, -1 when the variant has none     */
+    int right;  /* node index of right_fft, -1 when the variant has none                          */
+    size_t len; /* Recipe::len() of this node (src/plan.rs:190-230)                                */
+} mi355fft_recipe_node;
 typedef void (*mi355fft_twiddle_fn)(void* ctx, size_t index, size_t fft_len, double* re, double* im);
 typedef struct mi355fft_plan_options {
     size_t struct_size;
@@ -94,12 +130,20 @@ typedef struct mi355fft_plan_options {
     const void* bluestein_twiddles;
     const void* bluestein_multiplier;
     size_t bluestein_inner_len;
+    const mi355fft_recipe_node* recipe;
+    size_t recipe_nodes;
 } mi355fft_plan_options;
 int mi355fft_plan_create_ex(size_t len, int direction, int precision, const mi355fft_plan_options* options,
                             mi355fft_plan** out_plan);
 /* Inner (padded) transform length the GPU Bluestein path uses for `len` (0 when `len` is not planned through
  * Bluestein under MI355FFT_ALGO_BLUESTEIN): what a host planner must size inner_fft_multiplier for. */
 size_t mi355fft_bluestein_inner_len(size_t len, int precision);
+
+/* What the plan took from options.recipe: NONE = no recipe was given; FAMILY = the top-level family only (the GPU
+ * planner chose tilings / inner length itself); SPLIT = also the six-step split (pass heights) or the Bluestein inner
+ * length the recipe names. */
+enum { MI355FFT_RECIPE_STATUS_NONE = 0, MI355FFT_RECIPE_STATUS_FAMILY = 1, MI355FFT_RECIPE_STATUS_SPLIT = 2 };
+int mi355fft_plan_recipe_status(const mi355fft_plan* plan);
 
 /* `Length::len`, `Direction::fft_direction` (src/lib.rs:140-143, 174-177) */
 size_t mi355fft_plan_len(const mi355fft_plan* plan);

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmi355fft.so")
 
 EXPORTS = [
     "mi355fft_device_count", "mi355fft_init", "mi355fft_plan_create", "mi355fft_plan_create_ex", "mi355fft_bluestein_inner_len", "mi355fft_plan_destroy", "mi355fft_plan_len",
-    "mi355fft_plan_direction", "mi355fft_plan_precision", "mi355fft_scratch_len", "mi355fft_plan_describe",
+    "mi355fft_plan_direction", "mi355fft_plan_precision", "mi355fft_plan_recipe_status", "mi355fft_scratch_len", "mi355fft_plan_describe",
     "mi355fft_process_inplace_host", "mi355fft_process_outofplace_host", "mi355fft_process_immutable_host",
     "mi355fft_process_inplace_dev", "mi355fft_process_outofplace_dev", "mi355fft_process_immutable_dev",
     "mi355fft_plan_num_kernels", "mi355fft_plan_kernel_name", "mi355fft_profile_inplace_dev",
@@ -23,11 +23,16 @@ EXPORTS = [
 TWIDDLE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double))
 
 
+class RecipeNode(ctypes.Structure):
+    """mi355fft_recipe_node (include/mi355fft.h): one node of the host planner's flattened Recipe tree."""
+    _fields_ = [("kind", ctypes.c_int), ("left", ctypes.c_int), ("right", ctypes.c_int), ("len", ctypes.c_size_t)]
+
+
 class PlanOptions(ctypes.Structure):
     """mi355fft_plan_options (include/mi355fft.h)."""
     _fields_ = [("struct_size", ctypes.c_size_t), ("algorithm", ctypes.c_int), ("twiddle_fn", TWIDDLE_FN), ("twiddle_ctx", ctypes.c_void_p),
                 ("rader_inner_fft_data", ctypes.c_void_p), ("bluestein_twiddles", ctypes.c_void_p), ("bluestein_multiplier", ctypes.c_void_p),
-                ("bluestein_inner_len", ctypes.c_size_t)]
+                ("bluestein_inner_len", ctypes.c_size_t), ("recipe", ctypes.POINTER(RecipeNode)), ("recipe_nodes", ctypes.c_size_t)]
 
 
 def bind(lib):
@@ -44,6 +49,7 @@ def bind(lib):
     lib.mi355fft_plan_len.argtypes = [vp]
     lib.mi355fft_plan_direction.argtypes = [vp]
     lib.mi355fft_plan_precision.argtypes = [vp]
+    lib.mi355fft_plan_recipe_status.argtypes = [vp]
     lib.mi355fft_scratch_len.restype = sz
     lib.mi355fft_scratch_len.argtypes = [vp, ci]
     lib.mi355fft_plan_describe.argtypes = [vp, ctypes.c_char_p, sz]

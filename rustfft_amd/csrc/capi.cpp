@@ -264,10 +264,6 @@ int mi355fft_plan_create_ex(size_t len, int direction, int precision, const mi35
             return set_err(MI355FFT_ERR_INVALID_ARG, "mi355fft_plan_options.struct_size does not match this library");
         memcpy(&o, opts, opts->struct_size);  // fields past the caller's struct_size stay zero (older callers)
         if (o.algorithm < MI355FFT_ALGO_AUTO || o.algorithm > MI355FFT_ALGO_MIXED_RADIX) return set_err(MI355FFT_ERR_INVALID_ARG, "unknown algorithm");
-        if (o.rader_inner_fft_data && o.algorithm != MI355FFT_ALGO_RADER)
-            return set_err(MI355FFT_ERR_INVALID_ARG, "rader_inner_fft_data needs algorithm = MI355FFT_ALGO_RADER");
-        if ((o.bluestein_twiddles || o.bluestein_multiplier) && o.algorithm != MI355FFT_ALGO_BLUESTEIN)
-            return set_err(MI355FFT_ERR_INVALID_ARG, "Bluestein tables need algorithm = MI355FFT_ALGO_BLUESTEIN");
     }
     if (int rc = ensure_init()) return rc;
     mi355fft_plan* p = new mi355fft_plan();
@@ -281,6 +277,27 @@ int mi355fft_plan_create_ex(size_t len, int direction, int precision, const mi35
     p->p.opt_bs_tw = o.bluestein_twiddles;
     p->p.opt_bs_mul = o.bluestein_multiplier;
     p->p.opt_bs_inner = o.bluestein_inner_len;
+    if (o.recipe_nodes) {
+        if (!o.recipe || o.recipe_nodes > ((size_t)1 << 20)) {
+            delete p;
+            return set_err(MI355FFT_ERR_INVALID_ARG, "recipe_nodes without a recipe array (or an absurd node count)");
+        }
+        p->p.recipe.assign(o.recipe, o.recipe + o.recipe_nodes);
+        const char* why = "";
+        if (int rrc = apply_recipe(p->p, &why)) {
+            delete p;
+            return set_err(rrc, why);
+        }
+    }
+    // the finished tables belong to one family: the one `algorithm` names or the recipe's root implies
+    if (o.rader_inner_fft_data && p->p.algorithm != MI355FFT_ALGO_RADER) {
+        delete p;
+        return set_err(MI355FFT_ERR_INVALID_ARG, "rader_inner_fft_data needs algorithm = MI355FFT_ALGO_RADER");
+    }
+    if ((o.bluestein_twiddles || o.bluestein_multiplier) && p->p.algorithm != MI355FFT_ALGO_BLUESTEIN) {
+        delete p;
+        return set_err(MI355FFT_ERR_INVALID_ARG, "Bluestein tables need algorithm = MI355FFT_ALGO_BLUESTEIN");
+    }
     int rc = build_plan(p->p);
     // the caller's tables and callback are only borrowed for the duration of this call
     p->p.tw_fn = nullptr;
@@ -315,6 +332,7 @@ int mi355fft_plan_destroy(mi355fft_plan* plan) {
 size_t mi355fft_plan_len(const mi355fft_plan* plan) { return plan ? plan->p.len : 0; }
 int mi355fft_plan_direction(const mi355fft_plan* plan) { return plan ? plan->p.direction : 0; }
 int mi355fft_plan_precision(const mi355fft_plan* plan) { return plan ? plan->p.prec : 0; }
+int mi355fft_plan_recipe_status(const mi355fft_plan* plan) { return plan ? plan->p.recipe_status : 0; }
 size_t mi355fft_scratch_len(const mi355fft_plan*, int) { return 0; }
 
 int mi355fft_plan_describe(const mi355fft_plan* plan, char* buf, size_t cap) {

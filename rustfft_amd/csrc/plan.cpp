@@ -671,9 +671,29 @@ struct BluesteinChoice {
     const KernelEntry* k2 = nullptr;
     std::vector<size_t> radices;
 };
-static BluesteinChoice choose_bluestein(int prec, size_t n) {
+static bool choose_fused_radices(int prec, size_t need, std::vector<size_t>& out);
+// `prefer`: an inner length the host planner names (its recipe's inner_fft.len(), or the one its finished multiplier table is
+// sized for).  Taken when a kernel form exists for exactly that length, in the same order of forms; else the GPU planner's own.
+static BluesteinChoice choose_bluestein(int prec, size_t n, size_t prefer = 0, bool* preferred = nullptr) {
     BluesteinChoice c;
+    if (preferred) *preferred = false;
     if (n < 2) return c;
+    if (prefer >= 2 * n - 1 && prefer < ((size_t)1 << 31)) {
+        if (const KernelEntry* k = find_kernel(KIND_BLUESTEIN, prec, prefer)) {
+            c.form = 1, c.M = prefer, c.k1 = k;
+        } else if (find_kernel(KIND_BS2_FIRST, prec, prefer) && find_kernel(KIND_BS2_SECOND, prec, prefer)) {
+            c.form = 2, c.M = prefer, c.k1 = find_kernel(KIND_BS2_FIRST, prec, prefer), c.k2 = find_kernel(KIND_BS2_SECOND, prec, prefer);
+        } else if (choose_fused_radices(prec, prefer, c.radices)) {
+            size_t prod = 1;
+            for (size_t r : c.radices) prod *= r;
+            if (prod == prefer) c.form = 3, c.M = prefer;
+        }
+        if (c.form) {
+            if (preferred) *preferred = true;
+            return c;
+        }
+        c = BluesteinChoice();
+    }
     for (auto& e : registry())
         if (e.kind == KIND_BLUESTEIN && e.prec == prec && e.variant == 0 && (size_t)e.n >= 2 * n - 1 && (!c.k1 || e.n < c.k1->n)) c.k1 = &e;
     if (c.k1 && env_int("MI355FFT_VARIANT"))  // tuning: an alternative body for the same inner length
@@ -756,27 +776,62 @@ template <class T> static int build_plan_t(Plan& plan) {
             plan.passes.push_back(pd);
             return MI355FFT_OK;
         }
-        // the large-N passes address one transform with 32-bit element offsets
-        if (n < ((size_t)1 << 31) && choose_macro_radices(plan.prec, n, radices)) {
-            plan.kind = PLAN_MACRO;
+        // power-of-two column-tile passes over the given heights; `probe` only answers whether every pass has a kernel whose
+        // tile width divides the column count and the stride
+        auto macro_passes = [&](const std::vector<size_t>& rs, bool probe) -> int {
             size_t s = 1;
-            for (size_t p = 0; p < radices.size(); ++p) {
-                const size_t R = radices[p];
+            for (size_t p = 0; p < rs.size(); ++p) {
+                const size_t R = rs[p];
                 const KernelEntry* k = find_kernel(p == 0 ? KIND_K2_FIRST : KIND_K2_LATER, plan.prec, R);
-                if (k->prepare()) return MI355FFT_ERR_HIP;
+                if (!k) return MI355FFT_ERR_UNSUPPORTED;
                 const size_t M = n / R;
                 if (M % k->f != 0 || (p > 0 && s % k->f != 0)) return MI355FFT_ERR_UNSUPPORTED;
-                PassDesc pd{};
-                pd.k = k;
-                pd.m = (long long)M;
-                pd.s = (long long)s;
-                pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(*k), &rc);
-                if (rc) return rc;
-                if (p > 0 && (rc = build_lohi<T>(plan, pd, s * R))) return rc;
-                plan.passes.push_back(pd);
+                if (!probe) {
+                    if (k->prepare()) return MI355FFT_ERR_HIP;
+                    PassDesc pd{};
+                    pd.k = k;
+                    pd.m = (long long)M;
+                    pd.s = (long long)s;
+                    pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(*k), &rc);
+                    if (rc) return rc;
+                    if (p > 0 && (rc = build_lohi<T>(plan, pd, s * R))) return rc;
+                    plan.passes.push_back(pd);
+                }
                 s *= R;
             }
             return MI355FFT_OK;
+        };
+        auto general_passes = [&](const std::vector<size_t>& rs) -> int {
+            plan.kind = PLAN_MACRO;
+            std::vector<int> kinds(rs.size(), KIND_K2G_LATER);
+            kinds[0] = KIND_K2G_FIRST;
+            rc = append_general_passes<T>(plan, n, rs, kinds, nullptr, nullptr);
+            if (rc) return rc;
+            for (auto& pd : plan.passes) pd.row_n = 0;
+            return MI355FFT_OK;
+        };
+        // the host planner's six-step split (mi355fft_plan_options.recipe, a MixedRadix / GoodThomas root: mixed_radix.rs:53-158):
+        // its leaves become the pass heights when every one of them has a compiled column tile
+        if (plan.recipe_split.size() >= 2 && plan.recipe_split.size() <= 5 && n < ((size_t)1 << 31)) {
+            const std::vector<size_t>& rs = plan.recipe_split;
+            if (macro_passes(rs, true) == MI355FFT_OK) {
+                plan.kind = PLAN_MACRO;
+                plan.recipe_status = MI355FFT_RECIPE_STATUS_SPLIT;
+                return macro_passes(rs, false);
+            }
+            bool have = rs.size() <= 4;
+            for (size_t p = 0; p < rs.size() && have; ++p)
+                have = find_kernel(p == 0 ? KIND_K2G_FIRST : KIND_K2G_LATER, plan.prec, rs[p]) ||
+                       find_kernel(p == 0 ? KIND_K2R_FIRST : KIND_K2R_LATER, plan.prec, rs[p]);
+            if (have) {
+                plan.recipe_status = MI355FFT_RECIPE_STATUS_SPLIT;
+                return general_passes(rs);
+            }
+        }
+        // the large-N passes address one transform with 32-bit element offsets
+        if (n < ((size_t)1 << 31) && choose_macro_radices(plan.prec, n, radices)) {
+            plan.kind = PLAN_MACRO;
+            return macro_passes(radices, false);
         }
         // composite lengths above one workgroup: two to four general passes over 13-smooth tile heights (k2g_body) and prime tile
         // heights 37 .. 631 (k2r_body: Rader inside the tile) -- the reference's MixedRadix over Rader inner FFTs for lengths such
@@ -788,15 +843,7 @@ template <class T> static int build_plan_t(Plan& plan) {
             for (size_t r : radices) prime_tile = prime_tile || (r > 31 && is_prime_sz(r));
             general = prime_tile && (algo == MI355FFT_ALGO_MIXED_RADIX || env_int("MI355FFT_K2R_SMALL") == 1);
         }
-        if (general) {
-            plan.kind = PLAN_MACRO;
-            std::vector<int> kinds(radices.size(), KIND_K2G_LATER);
-            kinds[0] = KIND_K2G_FIRST;
-            rc = append_general_passes<T>(plan, n, radices, kinds, nullptr, nullptr);
-            if (rc) return rc;
-            for (auto& pd : plan.passes) pd.row_n = 0;
-            return MI355FFT_OK;
-        }
+        if (general) return general_passes(radices);
     }
     // prime length with a compiled Rader body (raders_algorithm.rs:65-124 precomputation, in f64)
     if (rader_ok) {
@@ -887,7 +934,9 @@ template <class T> static int build_plan_t(Plan& plan) {
         return MI355FFT_ERR_UNSUPPORTED;
     }
     if (!bluestein_ok) return MI355FFT_ERR_UNSUPPORTED;
-    const BluesteinChoice bc = choose_bluestein(plan.prec, n);
+    bool bs_preferred = false;
+    const BluesteinChoice bc = choose_bluestein(plan.prec, n, plan.opt_bs_mul ? plan.opt_bs_inner : plan.recipe_bs_inner, &bs_preferred);
+    if (bs_preferred && plan.recipe_bs_inner == bc.M) plan.recipe_status = MI355FFT_RECIPE_STATUS_SPLIT;
     if (bc.form == 1) {
         // any length that fits one workgroup: Bluestein over the smallest compiled M >= 2n - 1
         if (bc.k1->prepare()) return MI355FFT_ERR_HIP;
@@ -960,6 +1009,85 @@ template <class T> static int build_plan_t(Plan& plan) {
         }
     }
     return MI355FFT_ERR_UNSUPPORTED;
+}
+
+// The host planner's Recipe tree (mi355fft_plan_options.recipe; `enum Recipe`, src/plan.rs:134-188).  Checked the way the
+// reference's constructors assert, then reduced to what the GPU planner can use: the top-level family, the six-step split of a
+// MixedRadix / GoodThomas root, the inner length of a Bluesteins root.
+int apply_recipe(Plan& plan, const char** why) {
+    const std::vector<mi355fft_recipe_node>& r = plan.recipe;
+    const int n = (int)r.size();
+    auto bad = [&](const char* m) {
+        *why = m;
+        return MI355FFT_ERR_INVALID_ARG;
+    };
+    if (n == 0) return MI355FFT_OK;
+    auto child_ok = [&](int i, int c) { return c > i && c < n; };  // children follow their parent: no cycles, no sharing upward
+    for (int i = 0; i < n; ++i) {
+        const mi355fft_recipe_node& e = r[i];
+        switch (e.kind) {
+        case MI355FFT_RECIPE_DFT:
+        case MI355FFT_RECIPE_BUTTERFLY:
+            if (e.left != -1 || e.right != -1) return bad("recipe: a Dft / Butterfly node has no children");
+            break;
+        case MI355FFT_RECIPE_MIXED_RADIX:
+        case MI355FFT_RECIPE_GOOD_THOMAS:
+        case MI355FFT_RECIPE_MIXED_RADIX_SMALL:
+        case MI355FFT_RECIPE_GOOD_THOMAS_SMALL:
+            if (!child_ok(i, e.left) || !child_ok(i, e.right)) return bad("recipe: MixedRadix / GoodThomas needs left_fft and right_fft after the node");
+            if (r[e.left].len == 0 || r[e.right].len == 0 || r[e.left].len > e.len || (e.len / r[e.left].len) != r[e.right].len ||
+                e.len % r[e.left].len != 0)
+                return bad("recipe: left_fft.len() * right_fft.len() != len (mixed_radix.rs:53-62)");
+            break;
+        case MI355FFT_RECIPE_RADERS:
+            if (!child_ok(i, e.left) || e.right != -1) return bad("recipe: RadersAlgorithm needs inner_fft (left) only");
+            if (e.len < 3 || r[e.left].len != e.len - 1) return bad("recipe: RadersAlgorithm inner_fft.len() != len - 1 (raders_algorithm.rs:68-78)");
+            break;
+        case MI355FFT_RECIPE_BLUESTEINS:
+            if (!child_ok(i, e.left) || e.right != -1) return bad("recipe: BluesteinsAlgorithm needs inner_fft (left) only");
+            if (e.len == 0 || r[e.left].len < 2 * e.len - 1) return bad("recipe: BluesteinsAlgorithm inner_fft.len() < 2 len - 1 (bluesteins_algorithm.rs:55-61)");
+            break;
+        case MI355FFT_RECIPE_RADIXN:
+        case MI355FFT_RECIPE_RADIX4:
+            if (!child_ok(i, e.left) || e.right != -1) return bad("recipe: RadixN / Radix4 needs base_fft (left) only");
+            if (r[e.left].len == 0 || e.len % r[e.left].len != 0) return bad("recipe: RadixN / Radix4 len is not a multiple of base_fft.len()");
+            break;
+        default:
+            return bad("recipe: unknown node kind");
+        }
+    }
+    if (r[0].len != plan.len) return bad("recipe: the root's len differs from the plan's len");
+    int family = MI355FFT_ALGO_MIXED_RADIX;
+    if (r[0].kind == MI355FFT_RECIPE_DFT) family = MI355FFT_ALGO_AUTO;  // the planner's Dft(len) is its "no algorithm" answer (plan.rs:313-314)
+    if (r[0].kind == MI355FFT_RECIPE_RADERS) family = MI355FFT_ALGO_RADER;
+    if (r[0].kind == MI355FFT_RECIPE_BLUESTEINS) family = MI355FFT_ALGO_BLUESTEIN;
+    if (plan.algorithm == MI355FFT_ALGO_AUTO)
+        plan.algorithm = family;
+    else if (family != MI355FFT_ALGO_AUTO && plan.algorithm != family)
+        return bad("recipe: `algorithm` names another family than the recipe's root");
+    plan.recipe_status = MI355FFT_RECIPE_STATUS_FAMILY;
+    auto is_split = [](int k) {
+        return k == MI355FFT_RECIPE_MIXED_RADIX || k == MI355FFT_RECIPE_GOOD_THOMAS || k == MI355FFT_RECIPE_MIXED_RADIX_SMALL ||
+               k == MI355FFT_RECIPE_GOOD_THOMAS_SMALL;
+    };
+    plan.recipe_split.clear();
+    if (is_split(r[0].kind)) {
+        // leaves of the split sub-tree, right (height: transformed first, mixed_radix.rs:128-158) before left (width)
+        std::vector<int> stack{0};
+        while (!stack.empty()) {
+            const int i = stack.back();
+            stack.pop_back();
+            if (is_split(r[i].kind)) {
+                stack.push_back(r[i].left);  // popped second
+                stack.push_back(r[i].right);
+            } else {
+                plan.recipe_split.push_back(r[i].len);
+            }
+            if (plan.recipe_split.size() > 8) break;
+        }
+    }
+    plan.recipe_bs_inner = r[0].kind == MI355FFT_RECIPE_BLUESTEINS ? r[r[0].left].len : 0;
+    return MI355FFT_OK;
 }
 
 int build_plan(Plan& plan) {

@@ -87,6 +87,11 @@ struct Plan {
     const void* opt_bs_tw = nullptr;
     const void* opt_bs_mul = nullptr;
     size_t opt_bs_inner = 0;
+    // the host planner's Recipe tree (mi355fft_plan_options.recipe), copied; what apply_recipe() derived from it
+    std::vector<mi355fft_recipe_node> recipe;
+    std::vector<size_t> recipe_split;  // six-step pass heights a MixedRadix / GoodThomas root asks for (first pass first)
+    size_t recipe_bs_inner = 0;        // inner length a Bluesteins root names
+    int recipe_status = MI355FFT_RECIPE_STATUS_NONE;
     int device = -1;  // HIP device the tables live on (the device current at creation)
     std::mutex ws_mutex;
     std::map<void*, std::unique_ptr<StreamSlot>> slots;  // one execution slot (HBM workspace) per stream
@@ -114,6 +119,8 @@ struct Plan {
 };
 
 int build_plan(Plan& plan);
+// Validates plan.recipe against plan.len and derives family / split / inner length (0 or MI355FFT_ERR_INVALID_ARG; *why = reason)
+int apply_recipe(Plan& plan, const char** why);
 size_t bluestein_inner_len(size_t len, int prec);
 int execute(Plan& plan, const void* in, void* out, size_t batch, void* stream, int mode, Tracer* tr);
 

@@ -86,6 +86,8 @@ template <class T> class Fft {
     void process_immutable_device(const void* input, void* output, std::size_t batch, void* stream = nullptr) const {
         detail::check(mi355fft_process_immutable_dev(plan_, input, output, batch, stream));
     }
+    // what the plan took from options.recipe (MI355FFT_RECIPE_STATUS_*)
+    int recipe_status() const { return mi355fft_plan_recipe_status(plan_); }
     std::string describe() const {
         char buf[1024];
         detail::check(mi355fft_plan_describe(plan_, buf, sizeof buf));

@@ -21,6 +21,137 @@ SCRATCH_INPLACE, SCRATCH_OUTOFPLACE, SCRATCH_IMMUTABLE = 0, 1, 2
 ALGO_AUTO, ALGO_RADER, ALGO_BLUESTEIN, ALGO_MIXED_RADIX = 0, 1, 2, 3  # top-level Recipe family (src/plan.rs:134-188)
 
 
+RECIPE_STATUS_NONE, RECIPE_STATUS_FAMILY, RECIPE_STATUS_SPLIT = 0, 1, 2
+
+
+class Recipe:
+    """The host planner's `enum Recipe` (src/plan.rs:134-188) as a tree of (kind, len, children); `flatten()` gives the node
+    array of mi355fft_plan_options.recipe (root first, children after their parent).  `Recipe.parse` reads the Debug-like
+    notation `MixedRadix{<left>,<right>}`, `RadersAlgorithm{<inner>}`, `BluesteinsAlgorithm{len,<inner>}`,
+    `RadixN{[f0,f1,..],<base>}`, `Radix4{k,<base>}`, `Dft(len)`, `ButterflyN`."""
+    DFT, MIXED_RADIX, GOOD_THOMAS, MIXED_RADIX_SMALL, GOOD_THOMAS_SMALL, RADERS, BLUESTEINS, RADIXN, RADIX4, BUTTERFLY = range(10)
+    _SPLITS = {"MixedRadix": 1, "GoodThomasAlgorithm": 2, "MixedRadixSmall": 3, "GoodThomasAlgorithmSmall": 4}
+
+    def __init__(self, kind, len, left=None, right=None):
+        self.kind, self.len, self.left, self.right = int(kind), int(len), left, right
+
+    @staticmethod
+    def dft(len):
+        return Recipe(Recipe.DFT, len)
+
+    @staticmethod
+    def butterfly(len):
+        return Recipe(Recipe.BUTTERFLY, len)
+
+    @staticmethod
+    def mixed_radix(left, right, kind=MIXED_RADIX):
+        return Recipe(kind, left.len * right.len, left, right)
+
+    @staticmethod
+    def raders(inner):
+        return Recipe(Recipe.RADERS, inner.len + 1, inner)
+
+    @staticmethod
+    def bluesteins(len, inner):
+        return Recipe(Recipe.BLUESTEINS, len, inner)
+
+    @staticmethod
+    def radixn(factors, base):
+        n = base.len
+        for f in factors:
+            n *= int(f)
+        return Recipe(Recipe.RADIXN, n, base)
+
+    @staticmethod
+    def radix4(k, base):
+        return Recipe(Recipe.RADIX4, base.len << (2 * int(k)), base)
+
+    def flatten(self):
+        nodes, todo = [], [(self, None, None)]
+        while todo:
+            r, parent, side = todo.pop(0)
+            idx = len(nodes)
+            nodes.append([r.kind, -1, -1, r.len])
+            if parent is not None:
+                nodes[parent][side] = idx
+            if r.left is not None:
+                todo.append((r.left, idx, 1))
+            if r.right is not None:
+                todo.append((r.right, idx, 2))
+        arr = (_native.RecipeNode * len(nodes))()
+        for i, (k, l, rr, n) in enumerate(nodes):
+            arr[i].kind, arr[i].left, arr[i].right, arr[i].len = k, l, rr, n
+        return arr
+
+    @staticmethod
+    def parse(text):
+        text = text.replace(" ", "")
+        pos = 0
+
+        def number():
+            nonlocal pos
+            start = pos
+            while pos < len(text) and text[pos].isdigit():
+                pos += 1
+            return int(text[start:pos])
+
+        def expect(ch):
+            nonlocal pos
+            if text[pos] != ch:
+                raise ValueError(f"recipe: expected {ch!r} at {pos} in {text!r}")
+            pos += 1
+
+        def node():
+            nonlocal pos
+            start = pos
+            while pos < len(text) and text[pos].isalpha():
+                pos += 1
+            name = text[start:pos]
+            if name == "Radix" and text[pos:pos + 1] == "4":
+                name, pos = "Radix4", pos + 1
+            if name == "Butterfly":
+                return Recipe.butterfly(number())
+            if name == "Dft":
+                expect("(")
+                n = number()
+                expect(")")
+                return Recipe.dft(n)
+            expect("{")
+            if name in Recipe._SPLITS:
+                left = node()
+                expect(",")
+                right = node()
+                r = Recipe.mixed_radix(left, right, Recipe._SPLITS[name])
+            elif name == "RadersAlgorithm":
+                r = Recipe.raders(node())
+            elif name == "BluesteinsAlgorithm":
+                n = number()
+                expect(",")
+                r = Recipe.bluesteins(n, node())
+            elif name == "RadixN":
+                expect("[")
+                factors = [number()]
+                while text[pos] == ",":
+                    pos += 1
+                    factors.append(number())
+                expect("]")
+                expect(",")
+                r = Recipe.radixn(factors, node())
+            elif name == "Radix4":
+                k = number()
+                expect(",")
+                r = Recipe.radix4(k, node())
+            else:
+                raise ValueError(f"recipe: unknown variant {name!r}")
+            expect("}")
+            return r
+
+        r = node()
+        if pos != len(text):
+            raise ValueError(f"recipe: trailing text at {pos} in {text!r}")
+        return r
+
+
 class FftDirection(enum.IntEnum):  # src/lib.rs:146-171
     Forward = 0
     Inverse = 1
@@ -86,6 +217,10 @@ class Fft:
 
     def get_immutable_scratch_len(self):
         return self._lib.mi355fft_scratch_len(self._h, SCRATCH_IMMUTABLE)
+
+    def recipe_status(self):
+        """What the plan took from the host planner's recipe (RECIPE_STATUS_NONE / _FAMILY / _SPLIT)."""
+        return self._lib.mi355fft_plan_recipe_status(self._h)
 
     def describe(self):
         buf = ctypes.create_string_buffer(1024)
@@ -238,15 +373,21 @@ class FftPlannerHip:
         return self._cache[key]
 
     def plan_fft_with(self, len, direction, algorithm=ALGO_AUTO, twiddle_fn=None, rader_inner_fft_data=None,
-                      bluestein_twiddles=None, bluestein_multiplier=None):
-        """mi355fft_plan_create_ex: the HOST planner in charge -- it names the Recipe family and may supply its own
-        `compute_twiddle(index, fft_len) -> complex` (src/twiddles.rs:6-23, forward direction) and / or its finished Rader /
-        Bluestein tables (numpy arrays of the plan's complex dtype, in the plan's direction).  Not cached."""
+                      bluestein_twiddles=None, bluestein_multiplier=None, recipe=None):
+        """mi355fft_plan_create_ex: the HOST planner in charge -- it names the Recipe family (or hands over its whole `Recipe`
+        tree: a `Recipe` or its Debug-like text) and may supply its own `compute_twiddle(index, fft_len) -> complex`
+        (src/twiddles.rs:6-23, forward direction) and / or its finished Rader / Bluestein tables (numpy arrays of the plan's
+        complex dtype, in the plan's direction).  Not cached."""
         direction = FftDirection(direction)
         o = _native.PlanOptions()
         o.struct_size = ctypes.sizeof(_native.PlanOptions)
         o.algorithm = int(algorithm)
         keep = []
+        if recipe is not None:
+            nodes = (Recipe.parse(recipe) if isinstance(recipe, str) else recipe).flatten()
+            keep.append(nodes)
+            o.recipe = ctypes.cast(nodes, ctypes.POINTER(_native.RecipeNode))
+            o.recipe_nodes = nodes._length_
         if twiddle_fn is not None:
             def thunk(_ctx, index, fft_len, re, im):
                 w = complex(twiddle_fn(index, fft_len))

@@ -186,3 +186,121 @@ def check_host_planner_options(planner, oracle):
         check_fft_algorithm(fft, p, d, reference=oracle.plan(dtype, p, d), n=3)
     with pytest.raises(rustfft_amd.FftPanic, match="needs algorithm"):
         planner.plan_fft_with(1009, 0, rader_inner_fft_data=np.zeros(1008, dtype=dtype))
+
+
+def check_host_planner_recipe(planner, oracle, dtype=np.complex64, big=True):
+    """mi355fft_plan_options.recipe (include/mi355fft.h): the host planner hands over its whole Recipe tree (src/plan.rs:134-188).
+    The oracle's restatement of FftPlannerScalar::design_fft_for_len plays the Rust planner.  Checked: the family is the root's,
+    a MixedRadix root's leaves become the pass heights (right before left, mixed_radix.rs:128-158) when tiles exist, a
+    Bluesteins root's inner length is used when a kernel of that length exists, malformed trees are rejected the way the
+    reference's constructors assert, and every result matches the oracle's plan."""
+    import ctypes
+
+    import pytest
+
+    import rustfft_amd
+    from rustfft_amd import Recipe, _native
+    from rustfft_amd.planner import RECIPE_STATUS_FAMILY, RECIPE_STATUS_NONE, RECIPE_STATUS_SPLIT
+
+    assert planner.plan_fft(1024, 0).recipe_status() == RECIPE_STATUS_NONE
+    # 1. the scalar planner's own recipes, verbatim
+    for n, family in ((1200, "k1<1200"), (1009, "rader"), (4099, "bluestein"), (97, "rader"), (10403, "k2r"), (44100, "k2g")):
+        if n > 5000 and not big:
+            continue
+        text = oracle.recipe(n)
+        for d in (0, 1):
+            fft = planner.plan_fft_with(n, d, recipe=text)
+            assert family in fft.describe(), (n, text, fft.describe())
+            assert fft.recipe_status() >= RECIPE_STATUS_FAMILY
+            check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=2)
+    # the reference pads 4099 to 3 * 2^12 (plan.rs:649-657); the GPU's own ladder would take 5 * 2^11
+    text = oracle.recipe(4099)
+    assert text.startswith("BluesteinsAlgorithm{4099,") and Recipe.parse(text).left.len == 12288
+    fft = planner.plan_fft_with(4099, 0, recipe=text)
+    assert fft.recipe_status() == RECIPE_STATUS_SPLIT and "12288" in fft.describe(), fft.describe()
+    assert planner.bluestein_inner_len(4099) == 10240 and "10240" in planner.plan_fft(4099, 0).describe()
+    # an inner length no kernel has: the GPU keeps its own, the family stays
+    odd = Recipe.bluesteins(4099, Recipe.dft(8209))
+    fft = planner.plan_fft_with(4099, 0, recipe=odd)
+    assert fft.recipe_status() == RECIPE_STATUS_FAMILY and "10240" in fft.describe(), fft.describe()
+
+    # 2. six-step splits chosen by the host
+    def leaf(n):
+        return Recipe.dft(n)
+
+    cases = [
+        (1 << 16, Recipe.mixed_radix(leaf(64), leaf(1024)), ["<1024,", "<64,"]),       # height 1024 first, then width 64
+        (1 << 16, Recipe.mixed_radix(leaf(1024), leaf(64)), ["<64,", "<1024,"]),
+        (1 << 18, Recipe.mixed_radix(Recipe.mixed_radix(leaf(64), leaf(64)), leaf(64)), ["<64,", "<64,", "<64,"]),
+        (1517, Recipe.mixed_radix(Recipe.raders(leaf(36)), Recipe.raders(leaf(40))), ["k2rfirst<40,", "k2rlater<36,"]),  # 37 x 41: prime tiles (named by P - 1)
+        (36 * 4096, Recipe.mixed_radix(leaf(36), leaf(4096), Recipe.GOOD_THOMAS), None),  # no 4096-row tile of any kind: own split
+    ]
+    if big:
+        cases += [
+            (1 << 20, Recipe.mixed_radix(leaf(512), leaf(2048)), ["<2048,", "<512,"]),
+            (1 << 20, Recipe.mixed_radix(leaf(4096), leaf(256)), None),                  # no 4096-row tile: own split
+            (10403, Recipe.mixed_radix(Recipe.raders(leaf(102)), Recipe.raders(leaf(100))), ["k2rfirst<100,", "k2rlater<102,"]),
+        ]
+    for n, tree, want in cases:
+        assert tree.len == n
+        d = n % 2
+        fft = planner.plan_fft_with(n, d, recipe=tree)
+        desc = fft.describe()
+        if want is None:
+            assert fft.recipe_status() == RECIPE_STATUS_FAMILY, (n, desc)
+            assert desc == planner.plan_fft_with(n, d, algorithm=rustfft_amd.ALGO_MIXED_RADIX).describe()
+        else:
+            assert fft.recipe_status() == RECIPE_STATUS_SPLIT, (n, desc)
+            kernels = desc.split(" -> ")
+            assert len(kernels) == len(want) and all(w in k for w, k in zip(want, kernels)), (n, desc, want)
+        check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=2)
+
+    # 3. malformed trees: INVALID_ARG, never a wrong transform
+    def raw(nodes, n, algorithm=0):
+        arr = (_native.RecipeNode * len(nodes))()
+        for i, (k, l, r, ln) in enumerate(nodes):
+            arr[i].kind, arr[i].left, arr[i].right, arr[i].len = k, l, r, ln
+        o = _native.PlanOptions()
+        o.struct_size = ctypes.sizeof(_native.PlanOptions)
+        o.algorithm = algorithm
+        o.recipe = ctypes.cast(arr, ctypes.POINTER(_native.RecipeNode))
+        o.recipe_nodes = len(nodes)
+        h = ctypes.c_void_p()
+        rc = planner._lib.mi355fft_plan_create_ex(n, 0, planner._prec, ctypes.byref(o), ctypes.byref(h))
+        msg = planner._lib.mi355fft_last_error().decode()
+        if rc == 0:
+            planner._lib.mi355fft_plan_destroy(h)
+        return rc, msg
+
+    R = Recipe
+    bad = [
+        ([(R.MIXED_RADIX, 1, 2, 1024), (R.DFT, -1, -1, 32), (R.DFT, -1, -1, 16)], 1024, "left_fft.len() * right_fft.len() != len"),
+        ([(R.MIXED_RADIX, 0, 1, 1024), (R.DFT, -1, -1, 32)], 1024, "after the node"),          # a child that is its own parent
+        ([(R.MIXED_RADIX, 1, 5, 1024), (R.DFT, -1, -1, 32)], 1024, "after the node"),          # out of range
+        ([(R.RADERS, 1, -1, 1009), (R.DFT, -1, -1, 1024)], 1009, "inner_fft.len() != len - 1"),
+        ([(R.BLUESTEINS, 1, -1, 719), (R.DFT, -1, -1, 1024)], 719, "inner_fft.len() < 2 len - 1"),
+        ([(R.DFT, -1, -1, 512)], 1024, "root's len"),
+        ([(R.DFT, 1, -1, 1024), (R.DFT, -1, -1, 4)], 1024, "no children"),
+        ([(42, -1, -1, 1024)], 1024, "unknown node kind"),
+        ([(R.RADIX4, 1, -1, 1024), (R.BUTTERFLY, -1, -1, 3)], 1024, "multiple of base_fft"),
+    ]
+    for nodes, n, text in bad:
+        rc, msg = raw(nodes, n)
+        assert rc == 7 and text in msg, (nodes, rc, msg)
+    rc, msg = raw([(R.RADERS, 1, -1, 1009), (R.DFT, -1, -1, 1008)], 1009, algorithm=rustfft_amd.ALGO_BLUESTEIN)
+    assert rc == 7 and "another family" in msg
+    rc, msg = raw([(R.RADERS, 1, -1, 1009), (R.DFT, -1, -1, 1008)], 1009, algorithm=rustfft_amd.ALGO_RADER)
+    assert rc == 0
+    # a recipe for a composite length under a Raders root fails like RadersAlgorithm::new's assert (raders_algorithm.rs:68)
+    rc, msg = raw([(R.RADERS, 1, -1, 1025), (R.DFT, -1, -1, 1024)], 1025)
+    assert rc == 6, (rc, msg)
+
+    # 4. a binding compiled against the header BEFORE the recipe fields existed keeps working: fields beyond its struct_size
+    # are not read
+    o = _native.PlanOptions()
+    o.struct_size = _native.PlanOptions.recipe.offset
+    o.recipe_nodes = 12345  # garbage beyond the caller's struct
+    h = ctypes.c_void_p()
+    assert planner._lib.mi355fft_plan_create_ex(1024, 0, planner._prec, ctypes.byref(o), ctypes.byref(h)) == 0
+    assert planner._lib.mi355fft_plan_recipe_status(h) == RECIPE_STATUS_NONE
+    planner._lib.mi355fft_plan_destroy(h)

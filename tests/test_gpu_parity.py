@@ -684,6 +684,16 @@ def test_host_planner_options_on_device(planners, oracle):
 
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_host_planner_recipe_on_device(planners, oracle, dtype):
+    """mi355fft_plan_options.recipe on the real device: the oracle's restatement of FftPlannerScalar::design_fft_for_len
+    (src/plan.rs:312-323, 412-665) plays the Rust planner and hands its whole Recipe tree over; six-step splits it names become
+    the column-tile pass heights, its Bluestein inner length is used, malformed trees are rejected."""
+    from helpers import check_host_planner_recipe
+
+    check_host_planner_recipe(planners[np.dtype(dtype)], oracle, dtype, big=True)
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_large_primes_vs_oracle(planners, oracle, dtype):
     """Primes above one workgroup's reach with a smooth p - 1 (the reference plans RadersAlgorithm for them, src/plan.rs:636-665;
     raders_algorithm.rs:302-322 tests 112501 / 216569 / 417623 the same way): all four API modes against the oracle's plan and

@@ -1,4 +1,5 @@
-"""The Rust binding a maintainer would add lives in INTEGRATION.md as source (no rustc / cargo in this image or on the GPU
+"""The Rust binding lives in INTEGRATION.md (the in-tree arm a maintainer would add) and in shim/rustfft-mi355 (a standalone
+crate over the public `rustfft::Fft` trait) as source (no rustc / cargo in this image or on the GPU
 box, so it cannot be compiled here): this test keeps it honest against include/mi355fft.h -- every `extern "C"` function the
 document declares must exist in the header with the same arity, the same pointer-ness / constness and the same scalar
 types; every mi355fft_* function the Rust snippets CALL must be declared in one of the extern blocks; and the #[repr(C)]
@@ -14,6 +15,7 @@ C_TO_RUST = {
     "const mi355fft_plan_options*": "*const Mi355PlanOptions", "const char*": "*const std::ffi::c_char", "char*": "*mut std::ffi::c_char",
     "double*": "*mut f64", "size_t*": "*mut usize",
     "mi355fft_twiddle_fn": "Option<extern \"C\" fn(*mut c_void, usize, usize, *mut f64, *mut f64)>",
+    "const mi355fft_recipe_node*": "*const Mi355RecipeNode", "float*": "*mut f32",
 }
 
 
@@ -81,3 +83,70 @@ def test_plan_options_struct_matches_the_header():
     assert [f for f, _ in cfields] == [f for f, _ in rfields], (cfields, rfields)
     for (cn, ct), (rn, rt) in zip(cfields, rfields):
         assert C_TO_RUST[ct] == rt, (cn, ct, rt)
+
+
+# ---- shim/rustfft-mi355: the standalone crate ------------------------------------------------------------------------------
+CRATE = os.path.join(ROOT, "shim", "rustfft-mi355")
+
+
+def _strip_rust(text):
+    text = re.sub(r"//[^\n]*", "", text)
+    return re.sub(r"\bpub\s+", "", text)
+
+
+def _rust_struct_fields(text, name):
+    body = re.search(r"#\[repr\(C\)\](?:\s*#\[[^\]]*\])*\s*struct %s \{(.*?)\n\s*\}" % name, text, flags=re.S).group(1)
+    return [(a.split(":", 1)[0].strip(), re.sub(r"\s+", " ", a.split(":", 1)[1].strip())) for a in re.split(r",(?![^<(]*[>)])", body) if a.strip()]
+
+
+def _c_struct_fields(header, name):
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), re.sub(r"/\*.*?\*/", "", header, flags=re.S), flags=re.S).group(1)
+    fields = []
+    for line in body.split(";"):
+        line = norm_c(line)
+        if line:
+            mm = re.match(r"^(.*?[\*\s])(\w+)$", line)
+            fields.append((mm.group(2), norm_c(mm.group(1))))
+    return fields
+
+
+def test_crate_binds_every_function_of_the_header():
+    header = open(os.path.join(ROOT, "include", "mi355fft.h")).read()
+    src = _strip_rust(open(os.path.join(CRATE, "src", "lib.rs")).read())
+    protos, externs = c_prototypes(header), rust_externs(src)
+    assert set(externs) == set(protos), (sorted(set(protos) - set(externs)), sorted(set(externs) - set(protos)))
+    for name, (rret, rargs) in externs.items():
+        cret, cargs = protos[name]
+        assert C_TO_RUST[cret] == rret, (name, cret, rret)
+        assert len(cargs) == len(rargs), (name, cargs, rargs)
+        for ca, ra in zip(cargs, rargs):
+            assert C_TO_RUST[ca] == ra, (name, ca, ra)
+    # every ffi:: call in the crate (and its tests) names a declared function
+    used = set()
+    for root, _dirs, files in os.walk(CRATE):
+        for f in files:
+            if f.endswith(".rs"):
+                used |= set(re.findall(r"ffi::(mi355fft_\w+)", open(os.path.join(root, f)).read()))
+    assert used and used <= set(externs), sorted(used - set(externs))
+
+
+def test_crate_structs_and_constants_match_the_header():
+    header = open(os.path.join(ROOT, "include", "mi355fft.h")).read()
+    src = _strip_rust(open(os.path.join(CRATE, "src", "lib.rs")).read())
+    for cname, rname in (("mi355fft_plan_options", "Mi355PlanOptions"), ("mi355fft_recipe_node", "Mi355RecipeNode")):
+        cfields, rfields = _c_struct_fields(header, cname), _rust_struct_fields(src, rname)
+        assert [f for f, _ in cfields] == [f for f, _ in rfields], (cfields, rfields)
+        for (cn, ct), (rn, rt) in zip(cfields, rfields):
+            assert C_TO_RUST[ct] == rt, (cn, ct, rt)
+    cvals = {k: int(v) for k, v in re.findall(r"\b(MI355FFT_\w+)\s*=\s*(-?\d+)", header)}
+    for rname, val in re.findall(r"const (\w+): c_int = (-?\d+);", src):
+        assert cvals["MI355FFT_" + rname] == int(val), rname
+    recipe_kinds = {k for k in cvals if k.startswith("MI355FFT_RECIPE_") and not k.startswith("MI355FFT_RECIPE_STATUS_")}
+    assert {"MI355FFT_" + r for r, _ in re.findall(r"const (RECIPE_\w+): c_int = (\d+);", src)} == recipe_kinds
+
+
+def test_crate_layout():
+    for rel in ("Cargo.toml", "build.rs", "src/lib.rs", "tests/accuracy.rs", "tests/host_planner.rs"):
+        assert os.path.isfile(os.path.join(CRATE, rel)), rel
+    manifest = open(os.path.join(CRATE, "Cargo.toml")).read()
+    assert re.search(r'^rustfft\s*=', manifest, flags=re.M) and "[features]" in manifest

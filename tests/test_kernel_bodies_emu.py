@@ -464,6 +464,15 @@ def test_host_planner_options(emu_planner, oracle):
 
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_host_planner_recipe(emu_planner, oracle, dtype):
+    """mi355fft_plan_options.recipe on the kernel-body emulator: see helpers.check_host_planner_recipe (the same checks, plus
+    the large lengths, run on the device in tests/test_gpu_parity.py::test_host_planner_recipe_on_device)."""
+    from helpers import check_host_planner_recipe
+
+    check_host_planner_recipe(emu_planner(dtype), oracle, dtype, big=False)
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_prime_radices_17_to_31(emu_planner, oracle, dtype):
     """The reference's Butterfly17 .. Butterfly31 (src/algorithm/butterflies.rs:1582-6241) as in-register prime radices:
     lengths with such a factor run as mixed-radix kernels -- compiled schedules up to 4096 (f64: 2048), the run-time
