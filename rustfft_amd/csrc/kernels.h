@@ -684,9 +684,48 @@ template <class T> MI_HD void pointwise_elem(const PointwiseParams<T>& p, long l
 // MODE 1 -- one [F][PITCH] buffer: the coalesced load scatters x[t] straight to its convolution slot (perm_in holds the
 //   INVERSE map t -> j with g^(j+1) = t), both transforms read their inputs linearly from LDS, and the second transform
 //   scatters its outputs to their final positions in the same buffer.  Half the LDS, one LDS round trip fewer.
+// MODE 5 -- MODE 1 with the REGISTER HAND-OVER the one-kernel Bluestein uses: the second transform runs the reversed schedule, so
+//   the last sub-pass of the first leaves X[b + k NB] in exactly the registers the second's first radix-R butterflies read; the
+//   d[] multiply (and the x[0] / X[0] step) happens in registers and the spectrum never goes through LDS: one LDS write + read of
+//   p - 1 elements and one barrier fewer per row.  Rows sit at the larger pitch of the two schedules; x[0] / X[0] of row f live
+//   in slot F PITCH + f, behind every row, because the two schedules' exchange spans differ.
+// Body forms 2 / 3 / 4 are the rows loop (rader_rows_body).
+constexpr bool rader_rows_mode(int mode) { return mode >= 2 && mode <= 4; }
+template <class S> constexpr int rader5_pitch() {
+    using S2 = typename reversed_sched<S>::type;
+    return S::pitch() > S2::pitch() ? S::pitch() : S2::pitch();
+}
+template <class T, class S2> struct RaderRegSrc {
+    static constexpr bool kLoadsAll = true;
+    const cx<T>* MI_RESTRICT d;
+    cx<T>* spare;  // x[0] on entry, X[0] on exit, one slot per row
+    template <class SS> MI_HD void load_all(int f, int u, cx<T>* v) const {
+        static_assert(std::is_same<SS, S2>::value, "source of the reversed schedule");
+        constexpr int R = S2::R[0], NB = S2::nb(0), BPT = S2::bpt(0);
+        static_for<0, BPT>([&](auto M_) {
+            constexpr int m = M_;
+            const int b = u + m * S2::TPF;
+            if ((m + 1) * S2::TPF <= NB || b < NB) {
+                static_for<0, R>([&](auto K_) {
+                    constexpr int k = K_;
+                    const cx<T> val = v[m * R + k];
+                    cx<T> t = cconj(val * d[(unsigned)(b + k * NB)]);
+                    if constexpr (m == 0 && k == 0) {
+                        if (u == 0) {  // spectrum index 0 (raders_algorithm.rs:256-262)
+                            const cx<T> x0 = spare[f];
+                            t = t + cconj(x0);
+                            spare[f] = x0 + val;  // X[0]
+                        }
+                    }
+                    v[m * R + k] = t;
+                });
+            }
+        });
+    }
+};
 template <class T, class S, int F, int MODE, class X>
 MI_HD void rader_body(X& ex, const RaderParams<T>& p, long long block, void* lds) {
-    constexpr int M = S::N, P = S::N + 1, PITCH = S::pitch(), NT = F * S::TPF;
+    constexpr int M = S::N, P = S::N + 1, PITCH = (MODE == 5) ? rader5_pitch<S>() : S::pitch(), NT = F * S::TPF;
     const long long fft0 = block * F;
     const cx<T>* in = p.in;
     cx<T>* out = p.out;
@@ -698,12 +737,16 @@ MI_HD void rader_body(X& ex, const RaderParams<T>& p, long long block, void* lds
     cx<T>* work = (cx<T>*)lds;
     const long long rows_here = (batch - fft0) < F ? (batch - fft0) : F;
     const int valid = (int)(rows_here * P);
-    if constexpr (MODE == 1) {
+    if constexpr (MODE == 1 || MODE == 5) {
         // x[0], then X[0]: a slot past BOTH the exchange span (physical slots < phys(M-1) + 1) and the natural-order outputs
         // the last scatter writes (logical indices <= M = p - 1).  An unpadded layout has phys(M-1) + 1 == M, which IS the
         // target of the output with g^-(j+1) = p - 1: the slot must not be below p (round 2: a race that a rescheduling exposed).
-        constexpr int XS = (S::phys(M - 1) + 1 > P) ? S::phys(M - 1) + 1 : P;
-        static_assert(XS < PITCH && P <= PITCH, "row pitch must leave a spare slot");
+        // MODE 5 keeps it behind all rows instead (slot F PITCH + f, addressed as row 0's slot F PITCH: f PITCH + XS' with
+        // XS' = F PITCH + f - f PITCH is not a constant, so the accesses below go through xs_slot()).
+        constexpr int XS = (MODE == 5) ? 0 : (S::phys(M - 1) + 1 > P) ? S::phys(M - 1) + 1 : P;
+        static_assert(MODE == 5 || (XS < PITCH && P <= PITCH), "row pitch must leave a spare slot");
+        static_assert(P <= PITCH, "a row holds its p natural-order outputs");
+        auto xs_slot = [](int f) -> int { return (MODE == 5) ? F * PITCH + f : f * PITCH + XS; };
         // batches of eight elements per thread: all loads of a batch (element, slot) in flight before the first LDS write -- a
         // run-time loop costs one dependent memory round trip per element (F P / NT of them)
         ex.for_threads([&](int tid, cx<T>*) {
@@ -718,7 +761,7 @@ MI_HD void rader_body(X& ex, const RaderParams<T>& p, long long block, void* lds
                     const int t = tid + (q * CH + i) * NT, tc = t < F * P ? t : 0, f = tc / P, e = tc - f * P;
                     xr[i] = rowsp[t < valid ? t : 0];
                     const int pj = perm_in[e];  // unconditional (entry 0 of the inverse map is a spare 0): no branch around the load
-                    slot[i] = f * PITCH + (e == 0 ? XS : pj);
+                    slot[i] = (e == 0) ? xs_slot(f) : f * PITCH + pj;
                 });
                 static_for<0, nq>([&](auto I_) {
                     constexpr int i = I_;
@@ -734,22 +777,32 @@ MI_HD void rader_body(X& ex, const RaderParams<T>& p, long long block, void* lds
         });
         ex.barrier();
         auto src1 = [=](int f, int j) -> cx<T> { return work[f * PITCH + j]; };
-        auto dst1 = [=](int f, int j, cx<T> v) {
-            cx<T> t = cconj(v * dtab[j]);
-            if (j == 0) {
-                const cx<T> x0 = work[f * PITCH + XS];
-                t = t + cconj(x0);
-                work[f * PITCH + XS] = x0 + v;  // X[0]
-            }
-            work[f * PITCH + j] = t;
-        };
-        wg_fft<T, S, F, MAP_EF, MAP_EF, false, true>(ex, lds, p.tw, elem_src(src1), dst1);
-        ex.barrier();
         auto dst2 = [=](int f, int j, cx<T> v) {
-            if (j == 0) work[f * PITCH] = work[f * PITCH + XS];  // slot 0 is no target of the g^-j scatter
+            if (j == 0) work[f * PITCH] = work[xs_slot(f)];  // slot 0 is no target of the g^-j scatter
             work[f * PITCH + perm_out[j]] = cconj(v);
         };
-        wg_fft<T, S, F, MAP_EF, MAP_EF, false, true>(ex, lds, p.tw, elem_src(src1), dst2);
+        if constexpr (MODE == 5) {
+            using S2 = typename reversed_sched<S>::type;
+            static_assert(S2::R[0] == S::R[S::NP - 1] && S2::nb(0) == S::nb(S::NP - 1) && S2::bpt(0) == S::bpt(S::NP - 1) && S2::TPF == S::TPF,
+                          "register hand-over");
+            wg_fft<T, S, F, MAP_EF, MAP_EF, false, true>(ex, lds, p.tw, elem_src(src1), KeepInRegs{});
+            // (the barrier after the last gather of the first transform orders it before the second one's scatters; the natural-
+            // order outputs are written after the second transform's last gather + barrier, when no exchange data is live)
+            wg_fft<T, S2, F, MAP_EF, MAP_EF, false, false>(ex, lds, p.tw2, RaderRegSrc<T, S2>{dtab, work + F * PITCH}, dst2);
+        } else {
+            auto dst1 = [=](int f, int j, cx<T> v) {
+                cx<T> t = cconj(v * dtab[j]);
+                if (j == 0) {
+                    const cx<T> x0 = work[f * PITCH + XS];
+                    t = t + cconj(x0);
+                    work[f * PITCH + XS] = x0 + v;  // X[0]
+                }
+                work[f * PITCH + j] = t;
+            };
+            wg_fft<T, S, F, MAP_EF, MAP_EF, false, true>(ex, lds, p.tw, elem_src(src1), dst1);
+            ex.barrier();
+            wg_fft<T, S, F, MAP_EF, MAP_EF, false, true>(ex, lds, p.tw, elem_src(src1), dst2);
+        }
         ex.barrier();
         ex.for_threads([&](int tid, cx<T>*) {
             for (int t = tid; t < valid; t += NT) {

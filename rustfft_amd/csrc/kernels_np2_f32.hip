@@ -37,6 +37,12 @@ void register_np2_f32(std::vector<KernelEntry>& reg) {
     MI_RADERV(34, float, 32, 8, 2, 1008, 126, 16, 9, 7);
     MI_RADERV(35, float, 32, 16, 2, 1008, 144, 16, 9, 7);
     MI_RADERV(36, float, 32, 4, 2, 1008, 144, 16, 9, 7);
+    // tuning / emulator: side-by-side bodies with the register hand-over (rader_body MODE 5) for primes of every schedule shape
+    MI_RADERV(5, float, 32, 2, 5, 1008, 126, 14, 9, 8);
+    MI_RADERV(5, float, 32, 32, 5, 96, 8, 16, 6);
+    MI_RADERV(5, float, 32, 8, 5, 270, 30, 10, 9, 3);
+    MI_RADERV(5, float, 32, 1, 5, 4056, 312, 13, 13, 8, 3);
+    MI_RADERV(5, float, 32, 16, 5, 192, 16, 16, 12);
     MI_BS_LIST(float, 32);
     MI_BS(float, 32, 4, 512, 64, 8, 8, 8);
     MI_BS(float, 32, 1, 1024, 128, 8, 8, 16);  // 3.98 ns per row against 4.25 for 16 x 16 x 4 on one wave

@@ -15,12 +15,19 @@ void register_np2_f64(std::vector<KernelEntry>& reg) {
     MI_K1V(7, double, 64, 3, false, 1200, 80, 15, 16, 5);
     MI_K1V(8, double, 64, 2, false, 1200, 150, 8, 15, 10);
     MI_K1V(9, double, 64, 2, false, 1200, 100, 12, 10, 10);
-    // f64: the rows loop without the next-row prefetch (it would not fit 256 VGPRs): 2.6 TB/s against 2.06 (variant 1:
-    // four staged rows per workgroup) and 2.25 (variant 2: scatter on load, one row)
-    MI_RADER(double, 64, 8, 3, 1008, 144, 16, 9, 7);
+    // f64: scatter on load, one row per workgroup.  (Rounds 1 - 2: the rows loop without the next-row prefetch, 2.6 TB/s against
+    // 2.25 for this body; with the row loads batched -- round 3 -- this body runs 3.23 TB/s against 2.72 in a one-process A/B,
+    // profiles/r3/rader_mode1_back_f64.jsonl.)
+    MI_RADER(double, 64, 1, 1, 1008, 144, 16, 9, 7);
     MI_RADERV(1, double, 64, 4, 0, 1008, 144, 16, 9, 7);
-    MI_RADERV(2, double, 64, 1, 1, 1008, 144, 16, 9, 7);
+    MI_RADERV(2, double, 64, 8, 3, 1008, 144, 16, 9, 7);
     MI_RADERV(3, double, 64, 8, 2, 1008, 144, 16, 9, 7);
+    // tuning / emulator: side-by-side bodies with the register hand-over (rader_body MODE 5) for primes of every schedule shape
+    MI_RADERV(5, double, 64, 2, 5, 1008, 126, 14, 9, 8);
+    MI_RADERV(5, double, 64, 32, 5, 96, 8, 16, 6);
+    MI_RADERV(5, double, 64, 8, 5, 270, 30, 10, 9, 3);
+    MI_RADERV(5, double, 64, 1, 5, 4056, 312, 13, 13, 8, 3);
+    MI_RADERV(5, double, 64, 16, 5, 192, 16, 16, 12);
     MI_BS_LIST(double, 64);
     MI_BS(double, 64, 2, 512, 64, 8, 8, 8);
     MI_BS(double, 64, 2, 1024, 128, 8, 8, 16);  // 6.55 ns per row against 8.04 for 16 x 16 x 4

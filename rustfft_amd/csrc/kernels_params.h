@@ -74,6 +74,7 @@ template <class T> struct RaderParams {
     long long batch;
     int p;
     T sgn;
+    const cx<T>* tw2;      // MODE 5: sub-pass twiddles of the REVERSED schedule (the second transform)
 };
 
 // Run-time scheduled variants (dyn_engine.h): any 13-smooth length that fits one workgroup, and Rader for any

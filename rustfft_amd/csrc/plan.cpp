@@ -859,6 +859,13 @@ template <class T> static int build_plan_t(Plan& plan) {
             pd.k = &e;
             pd.d_tw = upload<T>(plan, build_subpass_twiddles<T>(e), &rc);
             if (rc) return rc;
+            {  // bodies with the register hand-over (kernels.h rader_body MODE 5) run the second inner transform with the sub-passes in
+               // reverse order; the other forms ignore this table
+                KernelEntry rev = e;
+                for (int i = 0; i < rev.np; ++i) rev.radix[i] = e.radix[rev.np - 1 - i];
+                pd.d_tw2 = upload<T>(plan, build_subpass_twiddles<T>(rev), &rc);
+                if (rc) return rc;
+            }
             if ((rc = rader_tables<T>(plan, pd, e.split, 0))) return rc;  // e.split: MODE >= 1 bodies scatter on load
             plan.passes.push_back(pd);
             return MI355FFT_OK;
@@ -1261,6 +1268,7 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         p.batch = (long long)batch;
         p.p = (int)plan.len;
         p.sgn = inverse ? (T)-1 : (T)1;
+        p.tw2 = (const cx<T>*)pd.d_tw2;
         grid = (long long)((batch + k.f - 1) / k.f);
         if (grid > kMaxGrid) return MI355FFT_ERR_INVALID_ARG;
         k.launch(&p, grid, stream);

@@ -419,12 +419,18 @@ def test_compiled_rader_bodies_every_form(emu_planner, oracle, dtype):
     leaves no spare slot past the exchange span (1297, 2003, 2081: the rows loop sizes its own buffer), the primes below 800
     that take a wider schedule to reach 64 threads per row, and f64 rows-loop bodies; both directions, ragged batch, against
     the reference's plan."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_rader_kernels as gen  # the per-prime choices are measured ones (its MODE1_BACK / F64_ROWS / WIDE_ROWS ... lists)
+
     planner = emu_planner(dtype)
     f32 = dtype == np.complex64
-    want = ({97: "m1", 127: "m1", 193: "m2", 257: "m2", 449: "m2", 541: "m2", 769: "m2", 811: "m2", 1201: "m2", 727: "m2", 883: "m2", 1297: "m2", 2003: "m4",
-             2081: "m4", 4051: "m4", 4057: "m4", 137: "m1", 647: "m1", 683: "m1", 2143: "m1"} if f32 else
-            {97: "m1", 127: "m1", 193: "m3", 257: "m3", 541: "m3", 727: "m3", 811: "m3", 883: "m3", 937: "m3", 1409: "m3", 911: "m1", 1201: "m3", 1297: "m3", 2081: "m3",
-             2801: "m1", 3697: "m3", 4057: "m1", 613: "m1", 2053: "m1", 3911: "m1"})  # (the last rows: p - 1 has a factor 17 .. 31)
+    prec = 32 if f32 else 64
+    primes = ([97, 127, 193, 257, 271, 449, 541, 769, 811, 1201, 727, 883, 1297, 2003, 2081, 4051, 4057, 137, 647, 683, 2143] if f32 else
+              [97, 127, 193, 257, 541, 727, 811, 883, 937, 1409, 911, 1201, 1297, 2081, 2801, 3697, 4057, 613, 2053, 3911])  # (the last ones: p - 1 has a factor 17 .. 31)
+    want = {p: "m%d" % gen.choose(p, prec)[1] for p in primes}
+    assert {"m1", "m2", "m4"} <= set(want.values()) if f32 else {"m1", "m3"} <= set(want.values()), want
     for p, form in want.items():
         for d in (0, 1):
             fft = planner.plan_fft(p, d)
@@ -512,6 +518,33 @@ def test_pair_fused_column_tiles(emu_planner, oracle):
                 check_fft_algorithm(fft, n, d, reference=oracle.plan(np.complex64, n, d), n=2)
     finally:
         del os.environ["MI355FFT_VARIANT"]
+
+
+@pytest.mark.parametrize("order", ["forward", "reverse"])
+def test_rader_register_handover(emu_planner, oracle, order):
+    """kernels.h rader_body MODE 5: the side-by-side Rader body whose second inner transform runs the reversed schedule, so the
+    d[] multiply and the x[0] / X[0] step (raders_algorithm.rs:256-262) happen in registers and the spectrum never goes
+    through LDS.  Primes of every schedule shape (two to four sub-passes, padded and unpadded layouts, different row pitches
+    of the two schedules), both precisions and directions, ragged batches, also with the threads of every phase in reverse
+    order (the x[0] / X[0] slots live behind all rows because the two schedules' exchange spans differ)."""
+    os.environ["MI355FFT_VARIANT"] = "5"
+    if order == "reverse":
+        os.environ["MI355_EMU_ORDER"] = "reverse"
+    try:
+        for dtype in (np.complex64, np.complex128):
+            planner = emu_planner(dtype)
+            for p in (97, 193, 271, 1009, 4057):
+                for d in (0, 1):
+                    fft = planner.plan_fft(p, d)
+                    assert fft.describe().startswith("rader<%d," % (p - 1)) and fft.describe().endswith("m5v5"), (p, fft.describe())
+                    check_fft_algorithm(fft, p, d, reference=oracle.plan(dtype, p, d), n=5)
+                    x = random_signal(37 * p, dtype)
+                    y = x.copy()
+                    fft.process(y)
+                    assert rel_l2(y, numpy_fft(x, p, d == 1)) < (5e-6 if dtype == np.complex64 else 1e-13), (p, d)
+    finally:
+        del os.environ["MI355FFT_VARIANT"]
+        os.environ.pop("MI355_EMU_ORDER", None)
 
 
 def test_thread_order_independence(emu_planner, oracle):

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--sizes-file", default="", help="file with comma- or whitespace-separated lengths")
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--gib", type=float, default=0.5)
+    ap.add_argument("--check", action="store_true", help="also compare the two builds' results on four rows (relative L2 of b against a)")
     ap.add_argument("--all", action="store_true", help="time a length even when both builds describe the same plan (a changed kernel body keeps its name)")
     args = ap.parse_args()
     dt, tdt, esz = (np.complex64, torch.complex64, 8) if args.dtype == "f32" else (np.complex128, torch.complex128, 16)
@@ -57,6 +58,17 @@ def main():
         ffts = [p.plan_fft_forward(n) for p in pl]
         if ffts[0].describe() == ffts[1].describe() and not args.all:
             continue
+        diff = None
+        if args.check:
+            rows = min(batch, 4)
+            src = torch.view_as_complex(torch.rand(rows * n, 2, dtype=torch.float32 if esz == 8 else torch.float64, device="cuda") * 10.0)
+            outs = []
+            for f in ffts:
+                y = src.clone()
+                f.process(y)
+                outs.append(y.to(torch.complex128))
+            torch.cuda.synchronize()
+            diff = float((outs[1] - outs[0]).norm() / outs[0].norm())
         for f in ffts:
             f.process(buf)
         best = [1e9, 1e9]
@@ -70,7 +82,7 @@ def main():
                 best[i] = min(best[i], e0.elapsed_time(e1) / 2)
             buf.mul_(1e-4)
         tb = [batch * 2 * n * esz / (t * 1e-3) / 1e12 for t in best]
-        print(json.dumps({"n": n, "a_TBps": round(tb[0], 3), "b_TBps": round(tb[1], 3), "b_over_a": round(tb[1] / tb[0], 3),
+        print(json.dumps({"n": n, "a_TBps": round(tb[0], 3), "b_TBps": round(tb[1], 3), "b_over_a": round(tb[1] / tb[0], 3), "rel_l2_b_vs_a": diff,
                           "plan_a": ffts[0].describe(), "plan_b": ffts[1].describe()}), flush=True)
 
 

@@ -92,12 +92,24 @@ F_TARGET = int(os.environ.get("RADER_F_TARGET", "256"))  # experiment knob: thre
 # (prec, p) -> rows per workgroup of the rows-side-by-side bodies (MODE 1) where half the rule's count ran > 4 % faster in a one-process
 # interleaved A/B of every prime (tools/ab_lengths.py --set primes, profiles/r2/rader_mode1_rows_ab_*.jsonl; twice the count loses 13 - 20 %)
 MODE1_ROWS = {(32, 37): 42, (32, 41): 32, (32, 43): 42, (32, 53): 32, (32, 61): 32, (32, 67): 21, (32, 73): 21, (32, 79): 18, (32, 113): 16, (32, 127): 9, (32, 197): 9, (32, 379): 3, (32, 521): 3, (32, 547): 3, (32, 677): 2, (64, 37): 42, (64, 41): 32, (64, 43): 42, (64, 53): 32, (64, 61): 32, (64, 67): 21, (64, 71): 25, (64, 73): 21, (64, 79): 18, (64, 97): 16, (64, 109): 10, (64, 113): 16, (64, 163): 7, (64, 197): 9, (64, 199): 7, (64, 271): 4, (64, 521): 3, (64, 547): 3, (64, 617): 2, (64, 661): 2}
+# (prec, p) -> back from the rows loop to rows side by side: the primes where the side-by-side body with batched row loads beat the
+# rows loop by > 4 % in a one-process A/B of every Rader prime (RADER_ALT=3 build; profiles/r3/rader_mode1_back_*.jsonl)
+MODE1_BACK = ({(32, p) for p in (193, 271, 281, 331, 337, 353, 397, 463, 751, 859, 1093, 1601, 1621, 1951, 2003, 2029, 2113, 2647, 2801, 2917, 2971, 3001, 3511, 3851, 4001, 4051, 4057)} |
+              {(64, p) for p in (193, 211, 241, 331, 337, 397, 401, 433, 463, 487, 491, 541, 577, 641, 727, 769, 811, 1051, 1153, 1171, 1249, 1297, 1321, 1373, 1471, 1621, 1783, 1801, 1951, 2251, 2593, 2663, 3169, 3697)})
 ALT = os.environ.get("RADER_ALT") == "1"  # experiment 1: the rows loop wherever it can be instantiated (A/B against the default choice)
 ALT2 = os.environ.get("RADER_ALT") == "2"  # experiment 2: one butterfly per thread, smallest radices, for the primes with >= 64 threads per row
+ALT3 = os.environ.get("RADER_ALT") == "3"  # experiment 3 (round 3, after the batched row loads made the side-by-side bodies 30 - 80 % faster): rows side by side wherever the layout allows
 
 
 def choose(p, prec):
     n = p - 1
+    if (ALT3 or (prec, p) in MODE1_BACK) and (prec, p) not in EXTRA31:
+        rad, tpf = g.schedule(n)
+        pitch, xs, emax, twreg = layout(n, rad, tpf)
+        esz = 8 if prec == 32 else 16
+        f = max(1, min(F_TARGET // tpf, (60 * 1024) // (pitch * esz)))
+        if xs < pitch and p <= pitch and pitch * esz * f <= 64 * 1024:
+            return (MODE1_ROWS.get((prec, p), f), 1, rad, tpf)
     if (prec, p) in EXTRA31:
         rad, tpf = g.schedule31(n)
         pitch, xs, emax, twreg = layout(n, rad, tpf)
@@ -140,6 +152,11 @@ def choose(p, prec):
     return (f, 0, rad, tpf)
 
 
+ALT5 = os.environ.get("RADER_ALT") == "5"  # experiment 5: every side-by-side body with the register hand-over (MODE 5)
+# (prec, p) -> MODE 5 instead of MODE 1 where the hand-over measured > 3 % faster (profiles/r3/rader_mode5_ab_*.jsonl)
+MODE5 = set()
+
+
 def main():
     s13 = set(g.smooth(4096, [2, 3, 5, 7, 11, 13]))
     primes13 = [p for p in range(17, 4097) if is_prime(p) and (p - 1) in s13 and p not in SKIP]
@@ -150,6 +167,8 @@ def main():
             lines = []
             for p in primes[ci::NFILES]:
                 f, mode, rad, tpf = choose(p, prec)
+                if mode == 1 and (ALT5 or (prec, p) in MODE5) and len(rad) >= 2:
+                    mode = 5
                 modes[mode] = modes.get(mode, 0) + 1
                 lines.append(f"    MI_RADER({ty}, {prec}, {f}, {mode}, {p - 1}, {tpf}, {', '.join(map(str, rad))});  // p = {p}")
             path = os.path.join(ROOT, "rustfft_amd", "csrc", f"kernels_rader_{tag}_{ci}.hip")
