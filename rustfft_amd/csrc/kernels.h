@@ -761,7 +761,13 @@ MI_HD void rader_body(X& ex, const RaderParams<T>& p, long long block, void* lds
                     const int t = tid + (q * CH + i) * NT, tc = t < F * P ? t : 0, f = tc / P, e = tc - f * P;
                     xr[i] = rowsp[t < valid ? t : 0];
                     const int pj = perm_in[e];  // unconditional (entry 0 of the inverse map is a spare 0): no branch around the load
-                    slot[i] = (e == 0) ? xs_slot(f) : f * PITCH + pj;
+                    // (a select between two computed values, not a branch: a branch here waits for pj and serialises the batch)
+                    if constexpr (MODE == 5) {
+                        const int s0 = F * PITCH + f, s1 = f * PITCH + pj;
+                        slot[i] = (e == 0) ? s0 : s1;
+                    } else {
+                        slot[i] = f * PITCH + (e == 0 ? XS : pj);
+                    }
                 });
                 static_for<0, nq>([&](auto I_) {
                     constexpr int i = I_;

@@ -684,6 +684,39 @@ def test_host_planner_options_on_device(planners, oracle):
 
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_every_compiled_rader_prime(planners, dtype):
+    """Every prime with a compiled Rader body (tools/gen_rader_kernels.py: 141 f32 / 148 f64 primes up to 4096, body form per
+    prime by measurement -- rows loop, rows side by side, side by side with the register hand-over between the two inner
+    transforms): both directions, a ragged five rows, against numpy in complex128 under the reference's gate
+    (tests/accuracy.rs:30-37) and a relative-L2 bound."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_rader_kernels as gen
+
+    planner = planners[np.dtype(dtype)]
+    prec = 32 if dtype == np.complex64 else 64
+    s13 = set(gen.g.smooth(4096, [2, 3, 5, 7, 11, 13]))
+    # (17 .. 31 are prime-radix butterflies, 1009 is the hand-tuned body of kernels_np2_*.hip)
+    primes = sorted({p for p in range(37, 4097) if gen.is_prime(p) and (p - 1) in s13} | {p for (pr, p) in gen.EXTRA31 if pr == prec})
+    assert len(primes) >= 136 and 1009 in primes
+    forms = set()
+    tol = 5e-6 if dtype == np.complex64 else 1e-13
+    for p in primes:
+        x = random_signal(5 * p, dtype, seed=p)
+        for d in (0, 1):
+            fft = planner.plan_fft(p, d)
+            assert fft.describe().startswith("rader<%d," % (p - 1)), (p, fft.describe())
+            forms.add(fft.describe().rsplit("m", 1)[1])
+            y = x.copy()
+            fft.process(y)
+            want = numpy_fft(x, p, d == 1)
+            assert compare_vectors(want.astype(dtype), y), (p, d, fft.describe())
+            assert rel_l2(y, want) < tol, (p, d, fft.describe(), rel_l2(y, want))
+    assert {"1", "5"} <= forms and (forms & {"2", "3", "4"}), forms
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_host_planner_recipe_on_device(planners, oracle, dtype):
     """mi355fft_plan_options.recipe on the real device: the oracle's restatement of FftPlannerScalar::design_fft_for_len
     (src/plan.rs:312-323, 412-665) plays the Rust planner and hands its whole Recipe tree over; six-step splits it names become
