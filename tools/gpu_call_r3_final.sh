@@ -1,14 +1,12 @@
 #!/bin/bash
-# Round 3, final validation on the GPU box: the whole -m gpu suite, a quick bench line (the driver takes the full one), the prime sweeps.
+# Round 3, final validation on the GPU box: the whole -m gpu suite and the prime sweeps (the driver takes the bench line).
 set -u
 OUT=gpurun_out/r3f
 mkdir -p $OUT
 python -m pytest tests -m gpu -q -x 2>&1 | tail -8 > $OUT/pytest_gpu.log
 cat $OUT/pytest_gpu.log
-python bench.py --no-pmc --no-cpu-baseline > $OUT/bench_quick.json 2> $OUT/bench_quick.stderr
-head -c 700 $OUT/bench_quick.json; echo
-timeout 80 python tools/prime_sweep.py > $OUT/primes_le_4096_f32.json 2>/dev/null
-timeout 80 python tools/prime_sweep.py --dtype f64 > $OUT/primes_le_4096_f64.json 2>/dev/null
+timeout 60 python tools/prime_sweep.py > $OUT/primes_le_4096_f32.json 2>/dev/null
+timeout 60 python tools/prime_sweep.py --dtype f64 > $OUT/primes_le_4096_f64.json 2>/dev/null
 python -c "
 import json
 for t in ('f32','f64'):
