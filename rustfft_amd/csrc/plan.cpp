@@ -1052,7 +1052,8 @@ int apply_recipe(Plan& plan, const char** why) {
             break;
         case MI355FFT_RECIPE_BLUESTEINS:
             if (!child_ok(i, e.left) || e.right != -1) return bad("recipe: BluesteinsAlgorithm needs inner_fft (left) only");
-            if (e.len == 0 || r[e.left].len < 2 * e.len - 1) return bad("recipe: BluesteinsAlgorithm inner_fft.len() < 2 len - 1 (bluesteins_algorithm.rs:55-61)");
+            if (e.len == 0 || e.len > ((size_t)-1) / 2 || r[e.left].len < 2 * e.len - 1)
+                return bad("recipe: BluesteinsAlgorithm inner_fft.len() < 2 len - 1 (bluesteins_algorithm.rs:55-61)");
             break;
         case MI355FFT_RECIPE_RADIXN:
         case MI355FFT_RECIPE_RADIX4:

@@ -483,6 +483,95 @@ def test_host_planner_recipe(emu_planner, oracle, dtype):
     check_host_planner_recipe(emu_planner(dtype), oracle, dtype, big=False)
 
 
+def test_random_recipe_trees(emu_planner):
+    """Random VALID recipe trees (random factorisation trees of random lengths, random split kinds, Rader / Bluestein roots where
+    the arithmetic allows) never produce a wrong transform: every accepted plan matches numpy in complex128, a refused one is
+    refused with UNSUPPORTED (no kernel for that family) -- and random CORRUPTIONS of a valid tree (a length or a child index
+    changed) are refused with INVALID_ARG or still compute the right transform of the plan's own length."""
+    import ctypes
+
+    import rustfft_amd
+    from rustfft_amd import Recipe, _native
+
+    rng = np.random.default_rng(20240917)
+    planner = emu_planner(np.complex64)
+
+    def is_prime(n):
+        return n > 1 and all(n % q for q in range(2, int(n**0.5) + 1))
+
+    def tree(n, depth=0):
+        divs = [q for q in range(2, int(n**0.5) + 1) if n % q == 0]
+        if divs and depth < 3 and rng.random() < 0.75:
+            q = int(rng.choice(divs))
+            kind = int(rng.choice([Recipe.MIXED_RADIX, Recipe.GOOD_THOMAS, Recipe.MIXED_RADIX_SMALL, Recipe.GOOD_THOMAS_SMALL]))
+            return Recipe.mixed_radix(tree(q, depth + 1), tree(n // q, depth + 1), kind)
+        if is_prime(n) and n > 3 and rng.random() < 0.5:
+            return Recipe.raders(tree(n - 1, depth + 1))
+        if n > 2 and rng.random() < 0.15:
+            m = 1 << int(np.ceil(np.log2(2 * n - 1)))
+            if m // 4 * 3 >= 2 * n - 1 and rng.random() < 0.5:
+                m = m // 4 * 3  # the reference's other inner-length family, 3 * 2^k (plan.rs:649-657)
+            return Recipe.bluesteins(n, Recipe.dft(m))
+        return Recipe.dft(n) if rng.random() < 0.5 else Recipe.butterfly(n)
+
+    def smooth_length():
+        n = 1
+        while n < 40:
+            n *= int(rng.choice([2, 2, 2, 3, 3, 5, 7, 11, 13]))
+        while n < 30000 and rng.random() < 0.6:
+            n *= int(rng.choice([2, 2, 3, 5, 7, 11, 13, 37, 41, 101]))
+        return n
+
+    lengths = ([int(v) for v in rng.integers(2, 20000, 15)] + [smooth_length() for _ in range(30)] +
+               [1517, 10403, 4096 * 3, 1 << 14, 1 << 16, 37 * 64, 1009, 4099, 719 * 2])
+    accepted = refused = 0
+    for n in lengths:
+        t = tree(n)
+        assert t.len == n
+        try:
+            fft = planner.plan_fft_with(n, n % 2, recipe=t)
+        except rustfft_amd.FftPanic as e:
+            assert e.status == 6, (n, e)  # MI355FFT_ERR_UNSUPPORTED: the family has no kernel at this length; never INVALID_ARG for a valid tree
+            refused += 1
+            continue
+        accepted += 1
+        x = random_signal(2 * n, np.complex64, seed=n)
+        y = x.copy()
+        fft.process(y)
+        assert rel_l2(y, numpy_fft(x, n, n % 2 == 1)) < 5e-6, (n, fft.describe())
+    assert accepted >= 25 and refused >= 1, (accepted, refused)
+
+    # corruptions of a valid tree
+    lib, prec = planner._lib, planner._prec
+    for trial in range(200):
+        n = int(rng.choice([1517, 10403, 1 << 14, 3 * 4096, 1200, 1009]))
+        nodes = tree(n).flatten()
+        k = len(nodes)
+        i = int(rng.integers(0, k))
+        what = int(rng.integers(0, 4))
+        if what == 0:
+            nodes[i].len = int(rng.integers(0, 3 * n))
+        elif what == 1:
+            nodes[i].left = int(rng.integers(-3, k + 3))
+        elif what == 2:
+            nodes[i].right = int(rng.integers(-3, k + 3))
+        else:
+            nodes[i].kind = int(rng.integers(-2, 14))
+        o = _native.PlanOptions()
+        o.struct_size = ctypes.sizeof(_native.PlanOptions)
+        o.recipe = ctypes.cast(nodes, ctypes.POINTER(_native.RecipeNode))
+        o.recipe_nodes = k
+        h = ctypes.c_void_p()
+        rc = lib.mi355fft_plan_create_ex(n, 0, prec, ctypes.byref(o), ctypes.byref(h))
+        assert rc in (0, 6, 7), (rc, trial)
+        if rc == 0:  # the corruption left a valid tree (or hit a field the variant ignores): the transform is still the length-n one
+            fft = rustfft_amd.Fft(lib, h, np.complex64)
+            x = random_signal(n, np.complex64, seed=trial)
+            y = x.copy()
+            fft.process(y)
+            assert rel_l2(y, numpy_fft(x, n, False)) < 5e-6, (n, trial, fft.describe())
+
+
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_prime_radices_17_to_31(emu_planner, oracle, dtype):
     """The reference's Butterfly17 .. Butterfly31 (src/algorithm/butterflies.rs:1582-6241) as in-register prime radices:
