@@ -82,3 +82,34 @@ def test_cpp_host_mirror_fails_loudly_without_gpu(hiplib):
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 3, (r.returncode, r.stdout, r.stderr)
     assert "no gfx950" in r.stdout
+
+
+def test_header_is_plain_c_and_layouts_match(tmp_path):
+    """include/mi355fft.h must be consumable from plain C (what bindgen / cgo / a C caller sees), and the struct layouts the
+    bindings mirror -- ctypes here, #[repr(C)] in shim/rustfft-mi355 and INTEGRATION.md -- must be the compiler's: sizes and
+    field offsets of mi355fft_plan_options and mi355fft_recipe_node from a C program against rustfft_amd/_native.py."""
+    import subprocess
+
+    from rustfft_amd import _native
+
+    fields = {"mi355fft_plan_options": [f for f, _ in _native.PlanOptions._fields_],
+              "mi355fft_recipe_node": [f for f, _ in _native.RecipeNode._fields_]}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "mi355fft.h"', "int main(void) {"]
+    for st, fs in fields.items():
+        src.append(f'    printf("{st} %zu\\n", sizeof({st}));')
+        for f in fs:
+            src.append(f'    printf("{st}.{f} %zu\\n", offsetof({st}, {f}));')
+    src += ["    return 0;", "}"]
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src) + "\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)]).decode().splitlines())
+    for st, cls in (("mi355fft_plan_options", _native.PlanOptions), ("mi355fft_recipe_node", _native.RecipeNode)):
+        assert int(got[st]) == ctypes.sizeof(cls), (st, got[st], ctypes.sizeof(cls))
+        for f, _ in cls._fields_:
+            assert int(got[f"{st}.{f}"]) == getattr(cls, f).offset, (st, f)
+    # the same header through a C++ compiler (the host mirror's view)
+    cpp = tmp_path / "layout.cpp"
+    cpp.write_text('#include "mi355fft.h"\nint main() { return sizeof(mi355fft_plan_options) == 0; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c", str(cpp), "-o", str(tmp_path / "layout_cpp.o")])
