@@ -154,9 +154,10 @@ def choose(p, prec):
 
 ALT5 = os.environ.get("RADER_ALT") == "5"  # experiment 5: every side-by-side body with the register hand-over (MODE 5)
 # (prec, p) -> MODE 5 instead of MODE 1 where the hand-over measured > 4 % faster in a one-process A/B of every side-by-side body
-# (RADER_ALT=5 build; profiles/r3/rader_mode5_ab_*.jsonl: f32 median +3.5 %, -36 .. +22 %; f64 median +2.5 %, -33 .. +50 %)
-MODE5 = ({(32, p) for p in (37, 41, 43, 67, 71, 101, 109, 127, 131, 151, 199, 281, 331, 521, 677, 751, 859, 2003, 2143, 2647, 2801, 2857, 2917, 2971, 3001, 3851, 4001, 4057)} |
-         {(64, p) for p in (43, 53, 71, 113, 193, 251, 379, 397, 463, 487, 521, 541, 547, 631, 701, 751, 769, 911, 1249, 1321, 1601, 1621, 1801, 2003, 2113, 2281, 2377, 2549, 2647, 2689, 2731, 2801, 2861, 2917, 3001, 3121, 3169, 3251, 3329, 3389, 3529, 3631, 3697, 3851, 4001)})
+# (RADER_ALT=5 build; profiles/r3/rader_mode5_ab_*.jsonl: f32 median +3.5 %, -36 .. +22 %; f64 median +2.5 %, -33 .. +50 %; a second
+# pass over the primes still on MODE 1, rader_mode5_ab2_*.jsonl, added 2 f32 / 13 f64 more at +4 .. 9 %)
+MODE5 = ({(32, p) for p in (37, 41, 43, 53, 67, 71, 101, 109, 127, 131, 137, 151, 199, 281, 331, 521, 677, 751, 859, 2003, 2143, 2647, 2801, 2857, 2917, 2971, 3001, 3851, 4001, 4057)} |
+         {(64, p) for p in (41, 43, 53, 71, 113, 127, 131, 193, 197, 211, 251, 331, 337, 379, 397, 463, 487, 491, 521, 541, 547, 631, 641, 701, 751, 769, 911, 1249, 1321, 1601, 1621, 1801, 1951, 2003, 2113, 2251, 2281, 2311, 2377, 2549, 2647, 2689, 2731, 2801, 2861, 2917, 2971, 3001, 3121, 3169, 3251, 3329, 3389, 3529, 3631, 3697, 3851, 4001)})
 
 
 def main():
