@@ -689,8 +689,8 @@ template <class T> MI_HD void pointwise_elem(const PointwiseParams<T>& p, long l
 //   d[] multiply (and the x[0] / X[0] step) happens in registers and the spectrum never goes through LDS: one LDS write + read of
 //   p - 1 elements and one barrier fewer per row.  Rows sit at the larger pitch of the two schedules; x[0] / X[0] of row f live
 //   in slot F PITCH + f, behind every row, because the two schedules' exchange spans differ.
-// Body forms 2 / 3 / 4 are the rows loop (rader_rows_body).
-constexpr bool rader_rows_mode(int mode) { return mode >= 2 && mode <= 4; }
+// Body forms 2 / 3 / 4 are the rows loop (rader_rows_body); 6 is the rows loop with the same register hand-over.
+constexpr bool rader_rows_mode(int mode) { return (mode >= 2 && mode <= 4) || mode == 6; }
 template <class S> constexpr int rader5_pitch() {
     using S2 = typename reversed_sched<S>::type;
     return S::pitch() > S2::pitch() ? S::pitch() : S2::pitch();
@@ -881,18 +881,55 @@ template <class T> MI_HD int reg_to_idx(const cx<T>& r) {
     else
         return (int)__builtin_bit_cast(long long, r.re);
 }
-template <class S> struct RaderRows {
+// HO (MODE 6): the register hand-over of rader_body MODE 5 inside the rows loop -- the second transform runs the reversed schedule S2
+// with ITS sub-pass factors in a second register block (TW1), the d[] factors already sit in the registers of the first
+// transform's last-pass outputs (D0), and the spectrum never goes through LDS.  A tuning variant so far (256-VGPR budget).
+template <class S, bool HO = false> struct RaderRows {
+    using S2 = typename reversed_sched<S>::type;
     static constexpr int M = S::N, P = S::N + 1, NT = S::TPF, EM = S::emax();
     static constexpr int NL = (P + NT - 1) / NT;  // elements of a row each thread loads / stores
-    static constexpr int TW0 = EM, D0 = TW0 + twreg_count<S>(), PO0 = D0 + EM, PI0 = PO0 + EM, XN0 = PI0 + NL, NREG = XN0 + NL;
-    // first slot past the exchange span AND past the natural-order outputs (indices <= M): x[0], then X[0]; XS + 1: dump slot
-    static constexpr int XS = (S::phys(M - 1) + 1 > P) ? S::phys(M - 1) + 1 : P;
+    static constexpr int TW0 = EM, TW1 = TW0 + twreg_count<S>(), D0 = TW1 + (HO ? twreg_count<S2>() : 0), PO0 = D0 + EM, PI0 = PO0 + EM,
+                         XN0 = PI0 + NL, NREG = XN0 + NL;
+    // first slot past the exchange span (of both schedules with HO) AND past the natural-order outputs (indices <= M): x[0], then
+    // X[0]; XS + 1: dump slot
+    static constexpr int SPAN = (HO && S2::phys(M - 1) > S::phys(M - 1)) ? S2::phys(M - 1) + 1 : S::phys(M - 1) + 1;
+    static constexpr int XS = (SPAN > P) ? SPAN : P;
     // LDS slots of the one row buffer: the exchange span, the natural-order outputs and the two spare slots
-    static constexpr int SLOTS = (S::pitch() > XS + 2) ? S::pitch() : XS + 2;
+    static constexpr int PITCH = (HO && S2::pitch() > S::pitch()) ? S2::pitch() : S::pitch();
+    static constexpr int SLOTS = (PITCH > XS + 2) ? PITCH : XS + 2;
 };
-template <class T, class S, int ROWS, bool PREFETCH, class X>
+// source of the reversed schedule inside the rows loop: d[] from the thread's registers, x[0] / X[0] through the spare slot
+template <class T, class S2, int D0> struct RaderRowsRegSrc {
+    static constexpr bool kLoadsAll = true;
+    cx<T>* spare;
+    template <class SS> MI_HD void load_all(int, int u, cx<T>* v) const {
+        static_assert(std::is_same<SS, S2>::value, "source of the reversed schedule");
+        constexpr int R = S2::R[0], NB = S2::nb(0), BPT = S2::bpt(0);
+        static_for<0, BPT>([&](auto M_) {
+            constexpr int m = M_;
+            const int b = u + m * S2::TPF;
+            if ((m + 1) * S2::TPF <= NB || b < NB) {
+                static_for<0, R>([&](auto K_) {
+                    constexpr int k = K_;
+                    const cx<T> val = v[m * R + k];
+                    cx<T> t = cconj(val * v[D0 + m * R + k]);
+                    if constexpr (m == 0 && k == 0) {
+                        if (u == 0) {
+                            const cx<T> x0 = spare[0];
+                            t = t + cconj(x0);
+                            spare[0] = x0 + val;  // X[0]
+                        }
+                    }
+                    v[m * R + k] = t;
+                });
+            }
+        });
+    }
+};
+template <class T, class S, int ROWS, bool PREFETCH, bool HO = false, class X>
 MI_HD void rader_rows_body(X& ex, const RaderParams<T>& p, long long block, void* lds) {
-    using L = RaderRows<S>;
+    using L = RaderRows<S, HO>;
+    using S2 = typename L::S2;
     constexpr int P = L::P, NT = L::NT, NL = L::NL, XS = L::XS;
     static_assert(XS + 1 < L::SLOTS && P <= L::SLOTS, "the row buffer holds two spare slots");
     const cx<T>* in = p.in;
@@ -903,6 +940,7 @@ MI_HD void rader_rows_body(X& ex, const RaderParams<T>& p, long long block, void
     const long long row_end = (row0 + ROWS < p.batch) ? row0 + ROWS : p.batch;
     ex.for_threads([&](int tid, cx<T>* v) {
         preload_twiddles<T, S, L::TW0>(v, tid, p.tw);
+        if constexpr (HO) preload_twiddles<T, S2, L::TW1>(v, tid, p.tw2);
         constexpr int LP = S::NP - 1, R = S::R[LP], NB = S::nb(LP), ST = S::stride(LP), BPT = S::bpt(LP);
         static_for<0, BPT>([&](auto M_) {
             constexpr int m = M_;
@@ -911,10 +949,23 @@ MI_HD void rader_rows_body(X& ex, const RaderParams<T>& p, long long block, void
             const int base = (bb / ST) * (ST * R) + (bb % ST);
             static_for<0, R>([&](auto K_) {
                 constexpr int k = K_;
-                v[L::D0 + m * R + k] = p.d[base + k * ST];
-                v[L::PO0 + m * R + k] = idx_to_reg<T>(p.perm_out[base + k * ST]);
+                v[L::D0 + m * R + k] = p.d[base + k * ST];  // factor of the first transform's last-pass output in slot m R + k
+                if constexpr (!HO) v[L::PO0 + m * R + k] = idx_to_reg<T>(p.perm_out[base + k * ST]);
             });
         });
+        if constexpr (HO) {  // the g^-j targets belong to the LAST pass of the second transform: the reversed schedule's
+            constexpr int LP2 = S2::NP - 1, R2 = S2::R[LP2], NB2 = S2::nb(LP2), ST2 = S2::stride(LP2), BPT2 = S2::bpt(LP2);
+            static_for<0, BPT2>([&](auto M_) {
+                constexpr int m = M_;
+                const int b = tid + m * S2::TPF;
+                const int bb = ((m + 1) * S2::TPF <= NB2 || b < NB2) ? b : 0;
+                const int base = (bb / ST2) * (ST2 * R2) + (bb % ST2);
+                static_for<0, R2>([&](auto K_) {
+                    constexpr int k = K_;
+                    v[L::PO0 + m * R2 + k] = idx_to_reg<T>(p.perm_out[base + k * ST2]);
+                });
+            });
+        }
         static_for<0, NL>([&](auto I_) {
             constexpr int i = I_;
             const int t = tid + i * NT;
@@ -960,9 +1011,16 @@ MI_HD void rader_rows_body(X& ex, const RaderParams<T>& p, long long block, void
             }
         });
         ex.barrier();
-        wg_fft<T, S, 1, MAP_EF, MAP_EF, false, true, 1, 0, L::TW0>(ex, lds, p.tw, elem_src(src), slot_dst(dst1));
-        ex.barrier();
-        wg_fft<T, S, 1, MAP_EF, MAP_EF, false, true, 1, 0, L::TW0>(ex, lds, p.tw, elem_src(src), slot_dst(dst2));
+        if constexpr (HO) {
+            static_assert(S2::R[0] == S::R[S::NP - 1] && S2::nb(0) == S::nb(S::NP - 1) && S2::bpt(0) == S::bpt(S::NP - 1) && S2::TPF == S::TPF,
+                          "register hand-over");
+            wg_fft<T, S, 1, MAP_EF, MAP_EF, false, true, 1, 0, L::TW0>(ex, lds, p.tw, elem_src(src), KeepInRegs{});
+            wg_fft<T, S2, 1, MAP_EF, MAP_EF, false, false, 1, 0, L::TW1>(ex, lds, p.tw2, RaderRowsRegSrc<T, S2, L::D0>{work + XS}, slot_dst(dst2));
+        } else {
+            wg_fft<T, S, 1, MAP_EF, MAP_EF, false, true, 1, 0, L::TW0>(ex, lds, p.tw, elem_src(src), slot_dst(dst1));
+            ex.barrier();
+            wg_fft<T, S, 1, MAP_EF, MAP_EF, false, true, 1, 0, L::TW0>(ex, lds, p.tw, elem_src(src), slot_dst(dst2));
+        }
         ex.barrier();
         ex.for_threads([&](int tid, cx<T>*) {
             static_for<0, NL>([&](auto I_) {

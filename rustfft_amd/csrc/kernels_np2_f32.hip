@@ -43,6 +43,14 @@ void register_np2_f32(std::vector<KernelEntry>& reg) {
     MI_RADERV(5, float, 32, 8, 5, 270, 30, 10, 9, 3);
     MI_RADERV(5, float, 32, 1, 5, 4056, 312, 13, 13, 8, 3);
     MI_RADERV(5, float, 32, 16, 5, 192, 16, 16, 12);
+    // tuning / emulator: the rows loop with the register hand-over (rader_rows_body HO, MODE 6)
+    MI_RADERV(6, float, 32, 8, 6, 1008, 126, 14, 9, 8);
+    MI_RADERV(61, float, 32, 8, 6, 1008, 144, 12, 7, 12);   // palindromic schedule: both transforms run the same radix order
+    MI_RADERV(62, float, 32, 16, 6, 1008, 126, 14, 9, 8);  // sixteen rows per workgroup
+    MI_RADERV(63, float, 32, 8, 6, 1008, 126, 8, 9, 14);
+    MI_RADERV(6, float, 32, 8, 6, 540, 108, 12, 9, 5);
+    MI_RADERV(6, float, 32, 8, 6, 4050, 450, 10, 9, 9, 5);
+    MI_RADERV(6, float, 32, 8, 6, 192, 64, 8, 8, 3);
     MI_BS_LIST(float, 32);
     MI_BS(float, 32, 4, 512, 64, 8, 8, 8);
     MI_BS(float, 32, 1, 1024, 128, 8, 8, 16);  // 3.98 ns per row against 4.25 for 16 x 16 x 4 on one wave

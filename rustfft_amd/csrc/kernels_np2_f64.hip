@@ -28,6 +28,11 @@ void register_np2_f64(std::vector<KernelEntry>& reg) {
     MI_RADERV(5, double, 64, 8, 5, 270, 30, 10, 9, 3);
     MI_RADERV(5, double, 64, 1, 5, 4056, 312, 13, 13, 8, 3);
     MI_RADERV(5, double, 64, 16, 5, 192, 16, 16, 12);
+    // tuning / emulator: the rows loop with the register hand-over (rader_rows_body HO, MODE 6)
+    MI_RADERV(6, double, 64, 8, 6, 1008, 126, 14, 9, 8);
+    MI_RADERV(6, double, 64, 8, 6, 540, 108, 12, 9, 5);
+    MI_RADERV(6, double, 64, 8, 6, 4050, 450, 10, 9, 9, 5);
+    MI_RADERV(6, double, 64, 8, 6, 192, 64, 8, 8, 3);
     MI_BS_LIST(double, 64);
     MI_BS(double, 64, 2, 512, 64, 8, 8, 8);
     MI_BS(double, 64, 2, 1024, 128, 8, 8, 16);  // 6.55 ns per row against 8.04 for 16 x 16 x 4

@@ -145,11 +145,11 @@ __global__ __launch_bounds__(F* S::TPF) void bluestein_kernel(BluesteinParams<T>
 template <class T, class S, int F, int MODE>
 // MODE 2: rows loop with next-row prefetch (>= 3 waves per SIMD in f32); MODE 3: without the prefetch; MODE 4: as MODE 2 for the
 // larger primes whose per-thread tables need up to 256 VGPRs (two waves per SIMD)
-__global__ __launch_bounds__((rader_rows_mode(MODE) ? 1 : F) * S::TPF, (MODE == 2 ? (sizeof(T) == 4 ? 3 : 2) : MODE == 3 ? (sizeof(T) == 4 ? 4 : 2) : MODE == 4 ? 2 : 1)) void rader_kernel(RaderParams<T> p) {
+__global__ __launch_bounds__((rader_rows_mode(MODE) ? 1 : F) * S::TPF, (MODE == 2 ? (sizeof(T) == 4 ? 3 : 2) : MODE == 3 ? (sizeof(T) == 4 ? 4 : 2) : (MODE == 4 || MODE == 6) ? 2 : 1)) void rader_kernel(RaderParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if constexpr (rader_rows_mode(MODE)) {  // F = rows pushed through one workgroup one after another
-        DevExecLoop<T, RaderRows<S>::NREG> ex;
-        rader_rows_body<T, S, F, MODE == 2 || MODE == 4>(ex, p, (long long)blockIdx.x, smem);
+        DevExecLoop<T, RaderRows<S, MODE == 6>::NREG> ex;
+        rader_rows_body<T, S, F, MODE == 2 || MODE == 4 || MODE == 6, MODE == 6>(ex, p, (long long)blockIdx.x, smem);
     } else {
         DevExec<T, regs_needed<S, false>()> ex;
         rader_body<T, S, F, MODE>(ex, p, (long long)blockIdx.x, smem);
@@ -177,7 +177,7 @@ template <class T, class S, int F, bool SPLIT = false, bool TW1 = false> constex
     return bluestein_lds_bytes<T, S, F, SPLIT, TW1>();  // exchange buffer of both schedules (+ the staged tables)
 }
 template <class T, class S, int F, int MODE> constexpr size_t rader_lds() {
-    if (rader_rows_mode(MODE)) return (size_t)RaderRows<S>::SLOTS * sizeof(cx<T>);  // one row at a time
+    if (rader_rows_mode(MODE)) return (size_t)RaderRows<S, MODE == 6>::SLOTS * sizeof(cx<T>);  // one row at a time
     if (MODE == 5) return (size_t)F * (rader5_pitch<S>() + 1) * sizeof(cx<T>);       // rows at the larger pitch of the two schedules + F spare slots
     return (size_t)F * (S::pitch() + (MODE >= 1 ? 0 : S::N + 1)) * sizeof(cx<T>);
 }
@@ -455,7 +455,7 @@ template <class T, class S, int F, bool SPLIT = false, bool TW1 = false> constex
     return bluestein_lds_bytes<T, S, F, SPLIT, TW1>();  // exchange buffer of both schedules (+ the staged tables)
 }
 template <class T, class S, int F, int MODE> constexpr size_t rader_lds() {
-    if (rader_rows_mode(MODE)) return (size_t)RaderRows<S>::SLOTS * sizeof(cx<T>);  // one row at a time
+    if (rader_rows_mode(MODE)) return (size_t)RaderRows<S, MODE == 6>::SLOTS * sizeof(cx<T>);  // one row at a time
     if (MODE == 5) return (size_t)F * (rader5_pitch<S>() + 1) * sizeof(cx<T>);       // rows at the larger pitch of the two schedules + F spare slots
     return (size_t)F * (S::pitch() + (MODE >= 1 ? 0 : S::N + 1)) * sizeof(cx<T>);
 }
@@ -495,8 +495,8 @@ template <class T, class S, int F, int MODE> KernelEntry make_rader(int prec, co
         std::vector<char> lds(rader_lds<T, S, F, MODE>() + 64, (char)0x5a);
         for (long long b = 0; b < grid; ++b) {
             if constexpr (rader_rows_mode(MODE)) {
-                HostExec<T, RaderRows<S>::NREG> ex(S::TPF);
-                rader_rows_body<T, S, F, MODE == 2 || MODE == 4>(ex, *(const RaderParams<T>*)params, b, lds.data());
+                HostExec<T, RaderRows<S, MODE == 6>::NREG> ex(S::TPF);
+                rader_rows_body<T, S, F, MODE == 2 || MODE == 4 || MODE == 6, MODE == 6>(ex, *(const RaderParams<T>*)params, b, lds.data());
             } else {
                 HostExec<T, regs_needed<S, false>()> ex(F * S::TPF);
                 rader_body<T, S, F, MODE>(ex, *(const RaderParams<T>*)params, b, lds.data());

@@ -621,23 +621,26 @@ def test_rader_register_handover(emu_planner, oracle, order):
     through LDS.  Primes of every schedule shape (two to four sub-passes, padded and unpadded layouts, different row pitches
     of the two schedules), both precisions and directions, ragged batches, also with the threads of every phase in reverse
     order (the x[0] / X[0] slots live behind all rows because the two schedules' exchange spans differ)."""
-    os.environ["MI355FFT_VARIANT"] = "5"
     if order == "reverse":
         os.environ["MI355_EMU_ORDER"] = "reverse"
     try:
-        for dtype in (np.complex64, np.complex128):
-            planner = emu_planner(dtype)
-            for p in (97, 193, 271, 1009, 4057):
-                for d in (0, 1):
-                    fft = planner.plan_fft(p, d)
-                    assert fft.describe().startswith("rader<%d," % (p - 1)) and fft.describe().endswith("m5v5"), (p, fft.describe())
-                    check_fft_algorithm(fft, p, d, reference=oracle.plan(dtype, p, d), n=5)
-                    x = random_signal(37 * p, dtype)
-                    y = x.copy()
-                    fft.process(y)
-                    assert rel_l2(y, numpy_fft(x, p, d == 1)) < (5e-6 if dtype == np.complex64 else 1e-13), (p, d)
+        # variant 5: the side-by-side body (MODE 5); variant 6: the rows loop with the same hand-over (MODE 6, a tuning variant: the
+        # reversed schedule's factors in a second register block, the g^-j targets taken from ITS last pass)
+        for variant, primes in (("5", (97, 193, 271, 1009, 4057)), ("6", (193, 541, 1009, 4051))):
+            os.environ["MI355FFT_VARIANT"] = variant
+            for dtype in (np.complex64, np.complex128):
+                planner = emu_planner(dtype)
+                for p in primes:
+                    for d in (0, 1):
+                        fft = planner.plan_fft(p, d)
+                        assert fft.describe().startswith("rader<%d," % (p - 1)) and fft.describe().endswith("m%sv%s" % (variant, variant)), (p, fft.describe())
+                        check_fft_algorithm(fft, p, d, reference=oracle.plan(dtype, p, d), n=5)
+                        x = random_signal(37 * p, dtype)
+                        y = x.copy()
+                        fft.process(y)
+                        assert rel_l2(y, numpy_fft(x, p, d == 1)) < (5e-6 if dtype == np.complex64 else 1e-13), (p, d)
     finally:
-        del os.environ["MI355FFT_VARIANT"]
+        os.environ.pop("MI355FFT_VARIANT", None)
         os.environ.pop("MI355_EMU_ORDER", None)
 
 
