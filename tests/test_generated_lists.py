@@ -1,0 +1,36 @@
+"""The generated kernel lists in rustfft_amd/csrc/ are what their generators produce today: a choice list edited in
+tools/gen_rader_kernels.py without regenerating the .hip files (or the other way round) would ship kernels the measurements
+behind the lists do not describe."""
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_rader_lists_match_the_generator():
+    import gen_rader_kernels as gen
+
+    assert not (gen.ALT or gen.ALT2 or gen.ALT3 or gen.ALT5), "RADER_ALT must not be set while testing"
+    s13 = set(gen.g.smooth(4096, [2, 3, 5, 7, 11, 13]))
+    primes13 = [p for p in range(17, 4097) if gen.is_prime(p) and (p - 1) in s13 and p not in gen.SKIP]
+    for tag, ty, prec in (("f32", "float", 32), ("f64", "double", 64)):
+        primes = sorted(primes13 + [p for (pr, p) in gen.EXTRA31 if pr == prec])
+        have = {}
+        for ci in range(gen.NFILES):
+            text = open(os.path.join(ROOT, "rustfft_amd", "csrc", f"kernels_rader_{tag}_{ci}.hip")).read()
+            for m in re.finditer(r"MI_RADER\((\w+), (\d+), (\d+), (\d+), ([\d, ]+)\);\s*// p = (\d+)", text):
+                assert m.group(1) == ty and int(m.group(2)) == prec
+                have[int(m.group(6))] = (int(m.group(3)), int(m.group(4)), [int(v) for v in m.group(5).split(",")])
+        assert sorted(have) == primes, (tag, sorted(set(primes) ^ set(have)))
+        for p in primes:
+            f, mode, rad, tpf = gen.choose(p, prec)
+            if mode == 1 and (prec, p) in gen.MODE5 and len(rad) >= 2:
+                mode = 5
+            assert have[p] == (f, mode, [p - 1, tpf] + list(rad)), (tag, p, have[p], (f, mode, rad, tpf))
+    # the measured lists only name primes that have a body, and a prime is in one list of a kind at most
+    for prec in (32, 64):
+        for name in ("MODE1_BACK", "MODE5"):
+            for (pr, p) in getattr(gen, name):
+                assert gen.is_prime(p) and 17 <= p <= 4096, (name, p)
