@@ -483,6 +483,42 @@ def test_host_planner_recipe(emu_planner, oracle, dtype):
     check_host_planner_recipe(emu_planner(dtype), oracle, dtype, big=False)
 
 
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_host_slices_need_only_element_alignment(emu_planner, oracle, dtype):
+    """A Rust `&mut [Complex<T>]` guarantees align_of::<T>() only -- 4 bytes for Complex<f32>, 8 for Complex<f64> (SURVEY
+    section 8(b) layout rule): the host-slice entry points stage through plain byte copies, so a buffer that starts one
+    float past a 16-byte boundary works in all three modes (single-kernel and multi-pass plans, multi-row batches)."""
+    real = np.float32 if dtype == np.complex64 else np.float64
+    planner = emu_planner(dtype)
+    for n in (1009, 1200, 1 << 16):
+        rows = 3
+        for d in (0, 1):
+            fft = planner.plan_fft(n, d)
+            x = random_signal(rows * n, dtype, seed=n + d)
+            want = x.copy()
+            oracle.plan(dtype, n, d).process(want)
+
+            def skewed(values=None):
+                raw = np.zeros(2 * rows * n + 8, dtype=real)
+                base = raw.ctypes.data
+                start = ((-base) % 16) // raw.itemsize + 1  # element index just past a 16-byte boundary
+                view = raw[start:start + 2 * rows * n].view(dtype)
+                assert view.ctypes.data % 16 == raw.itemsize and view.flags.c_contiguous
+                if values is not None:
+                    view[:] = values
+                return view
+
+            a = skewed(x)
+            fft.process(a)
+            assert compare_vectors(want, a), (n, d, "in place")
+            src, dst = skewed(x), skewed()
+            fft.process_outofplace_with_scratch(src, dst, np.zeros(fft.get_outofplace_scratch_len(), dtype=dtype))
+            assert np.array_equal(dst, a), (n, d, "out of place")
+            src, dst = skewed(x), skewed()
+            fft.process_immutable_with_scratch(src, dst, np.zeros(fft.get_immutable_scratch_len(), dtype=dtype))
+            assert np.array_equal(dst, a) and np.array_equal(src, x), (n, d, "immutable")
+
+
 def test_random_recipe_trees(emu_planner):
     """Random VALID recipe trees (random factorisation trees of random lengths, random split kinds, Rader / Bluestein roots where
     the arithmetic allows) never produce a wrong transform: every accepted plan matches numpy in complex128, a refused one is
