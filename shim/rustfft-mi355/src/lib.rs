@@ -348,7 +348,7 @@ mod hip {
 
     extern "C" fn twiddle_thunk<T: FftNum>(ctx: *mut c_void, index: usize, fft_len: usize, re: *mut f64, im: *mut f64) {
         // ctx carries the fn pointer itself
-        let f: fn(usize, usize) -> Complex<T> = unsafe { std::mem::transmute(ctx) };
+        let f: fn(usize, usize) -> Complex<T> = unsafe { std::mem::transmute::<*mut c_void, fn(usize, usize) -> Complex<T>>(ctx) };
         let w = f(index, fft_len);
         unsafe {
             *re = w.re.to_f64().unwrap();
@@ -410,7 +410,7 @@ mod hip {
                     ffi::ALGO_AUTO // a recipe, when present, names the family
                 },
                 twiddle_fn: options.twiddle.map(|_| twiddle_thunk::<T> as extern "C" fn(*mut c_void, usize, usize, *mut f64, *mut f64)),
-                twiddle_ctx: options.twiddle.map_or(std::ptr::null_mut(), |f| f as *mut c_void),
+                twiddle_ctx: options.twiddle.map_or(std::ptr::null_mut(), |f| f as usize as *mut c_void),
                 rader_inner_fft_data: as_ptr(options.rader_inner_fft_data),
                 bluestein_twiddles: as_ptr(options.bluestein_twiddles),
                 bluestein_multiplier: as_ptr(options.bluestein_multiplier),
