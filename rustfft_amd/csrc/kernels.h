@@ -133,17 +133,19 @@ template <class T, bool FIRST, int ABL = 0, int F_ = 0> struct K2Src {
         static_assert(NB % TPF == 0 && NB == BPT * TPF, "column-tile schedules fill every thread");
         // 32-bit element offsets from the (workgroup-uniform) transform base: one VGPR per address instead of two
         const unsigned col = b0 + (unsigned)f;
-        static_for<0, BPT>([&](auto M_) {
-            constexpr int m = M_;
-            static_for<0, R>([&](auto K_) {
-                constexpr int k = K_;
-                const unsigned row = (unsigned)(u + m * TPF + k * NB);
-                if constexpr ((ABL & 16) != 0)
-                    v[m * R + k] = ld_nt(in + (col + row * M));
-                else
-                    v[m * R + k] = in[col + row * M];
+        if constexpr ((ABL & 4096) == 0) {  // (two columns per lane: k2_body has loaded the rows of both columns already)
+            static_for<0, BPT>([&](auto M_) {
+                constexpr int m = M_;
+                static_for<0, R>([&](auto K_) {
+                    constexpr int k = K_;
+                    const unsigned row = (unsigned)(u + m * TPF + k * NB);
+                    if constexpr ((ABL & 16) != 0)
+                        v[m * R + k] = ld_nt(in + (col + row * M));
+                    else
+                        v[m * R + k] = in[col + row * M];
+                });
             });
-        });
+        }
         if constexpr (FIRST || (ABL & 1)) {
             static_for<0, BPT * R>([&](auto I_) { v[decltype(I_)::value].im *= sgn_in; });
         } else {
@@ -211,7 +213,61 @@ MI_HD void k2_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     };
     // first pass: lanes walk across the tile's columns on the way in and along each sequence on the way
     // out (the F*R output block is contiguous); later passes: across columns both ways
-    wg_fft<T, S, F, (ABL & 64) ? MAP_FFP : MAP_FF, FIRST ? MAP_EF : MAP_FF, SPLIT, false, k2_pitch_mod(F), (ABL & 15), -1, false, k2_twl<ABL, S::NP>()>(ex, lds, p.tw, src, dst);
+    if constexpr ((ABL & 4096) != 0) {
+        // Two columns per lane (tuning; launch.h DevExecPair): virtual threads 2 t and 2 t + 1 are the columns f, f + 1 of the same
+        // rows and run on one physical thread, whose register array holds the even column's values at v[i] and the odd column's at
+        // v[NREG + i].  The even one fetches both columns' rows as 16-byte accesses in a phase of its own (no barrier: its partner
+        // is the same thread; the emulator runs phases one after the other), the engine then applies the inter-pass factors
+        // (K2Src skips its loads), and the later passes store both columns' outputs as 16 bytes the same way.
+        constexpr int NREG = regs_needed<S, SPLIT>(), R0 = S::R[0], NB0 = S::nb(0), BPT0 = S::bpt(0), TPF = S::TPF;
+        static_assert(F % 2 == 0, "pairs of adjacent columns");
+        struct alignas(2 * sizeof(cx<T>)) cx2 {
+            cx<T> a, b;
+        };
+        ex.for_threads([&](int tid, cx<T>* v) {
+            int f, u;
+            map_tid<MAP_FF, F, TPF>(tid, f, u);
+            if ((f & 1) == 0) {
+                const unsigned col = b0 + (unsigned)f;
+                static_for<0, BPT0>([&](auto M_) {
+                    constexpr int m = M_;
+                    static_for<0, R0>([&](auto K_) {
+                        constexpr int k = K_;
+                        const unsigned row = (unsigned)(u + m * TPF + k * NB0);
+                        const cx2 q = *(const cx2*)(in + (col + row * M));
+                        v[m * R0 + k] = q.a;
+                        v[NREG + m * R0 + k] = q.b;
+                    });
+                });
+            }
+        });
+        if constexpr (FIRST) {
+            wg_fft<T, S, F, MAP_FF, MAP_EF, SPLIT, false, k2_pitch_mod(F), (ABL & 15), -1, false, k2_twl<ABL, S::NP>()>(ex, lds, p.tw, src, dst);
+        } else {
+            wg_fft<T, S, F, MAP_FF, MAP_FF, SPLIT, false, k2_pitch_mod(F), (ABL & 15), -1, false, k2_twl<ABL, S::NP>()>(ex, lds, p.tw, src, KeepInRegs{});
+            constexpr int LP = S::NP - 1, RL = S::R[LP], NBL = S::nb(LP), STL = S::stride(LP), BPTL = S::bpt(LP);
+            ex.for_threads([&](int tid, cx<T>* v) {
+                int f, u;
+                map_tid<MAP_FF, F, TPF>(tid, f, u);
+                if ((f & 1) == 0) {
+                    static_for<0, BPTL>([&](auto M_) {
+                        constexpr int m = M_;
+                        const int b = u + m * TPF;
+                        const int base = (b / STL) * (STL * RL) + (b % STL);
+                        static_for<0, RL>([&](auto K_) {
+                            constexpr int k = K_;
+                            cx2 q{v[m * RL + k], v[NREG + m * RL + k]};
+                            q.a.im *= sgn_out;
+                            q.b.im *= sgn_out;
+                            *(cx2*)(out + (obase + (unsigned)f + (unsigned)(base + k * STL) * s32)) = q;
+                        });
+                    });
+                }
+            });
+        }
+    } else {
+        wg_fft<T, S, F, (ABL & 64) ? MAP_FFP : MAP_FF, FIRST ? MAP_EF : MAP_FF, SPLIT, false, k2_pitch_mod(F), (ABL & 15), -1, false, k2_twl<ABL, S::NP>()>(ex, lds, p.tw, src, dst);
+    }
 }
 // LDS bytes of a column-tile workgroup: the exchange buffer + the staged twiddle tables
 template <class T, class S, int F, bool SPLIT, int ABL> constexpr size_t k2_lds_bytes() {

@@ -47,6 +47,13 @@ void register_k2_f32(std::vector<KernelEntry>& reg) {
     MI_K2P_LATER(float, 32, 32, true, 512, 16, 8, 8, 8);
     reg.back().variant = 12;
 #endif
+    // tuning 50 - 53: two columns per lane (DevExecPair, ABL bit 4096) with the staged tables (128): the tile as 16 columns x 64
+    // virtual slots of 16 values, 512 physical threads x 2 x 16 values -- the same registers, waves and LDS as the shipped tile,
+    // row loads / stores of 16 bytes per lane; 52 / 53: the 2048-row tile the same way (1024 physical threads)
+    MI_K2ABL(50, 4224, float, 32, 16, true, 1024, 64, 8, 8, 16);
+    MI_K2ABL(51, 4224, float, 32, 16, true, 1024, 64, 16, 8, 8);
+    MI_K2ABL(52, 4096, float, 32, 16, true, 2048, 128, 8, 16, 16);
+    MI_K2ABL(53, 4096, float, 32, 16, true, 2048, 128, 16, 16, 8);
     MI_K2V(10, float, 32, 16, true, 1024, 32, 32, 32);     // tuning: two radix-32 sub-passes, one exchange (the later pass spills)
     MI_K2V(11, float, 32, 16, true, 1024, 32, 4, 16, 16);  // tuning: radix-4 first sub-pass (eight butterflies per thread)
     // ablation probes of the default 1024-row tile (wrong results by design; MI355FFT_VARIANT=5..8, tuning only)

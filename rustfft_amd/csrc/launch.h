@@ -36,6 +36,21 @@ template <class T, int NREG> struct DevExec {
         }
     }
 };
+// Two VIRTUAL threads per physical thread (tuning: ABL bit 4096 of the column-tile kernels): the engine sees a workgroup of
+// 2 x blockDim threads; physical thread t runs virtual threads 2 t and 2 t + 1 one after the other in every phase, each on its own
+// half of the register array.  With the column-fastest map these are two ADJACENT columns of the tile (same rows), so the row
+// loads / stores of the pair are 16 contiguous bytes -- the "two columns per lane" form of the tile skeleton
+// (tools/membench/skel.hip v4: + 1.4 .. 6 % on the later-pass shape) without a second engine.
+template <class T, int NREG> struct DevExecPair {
+    cx<T> v[2 * NREG];
+    template <class Fn> __device__ __forceinline__ void for_threads(Fn&& fn) {
+        fn(2 * (int)threadIdx.x, v);
+        fn(2 * (int)threadIdx.x + 1, v + NREG);
+    }
+    __device__ __forceinline__ void barrier() { __syncthreads(); }
+    __device__ __forceinline__ void relaunder() {}
+    __device__ __forceinline__ void pair_swap() {}
+};
 // Executor for bodies that loop over many sequences: relaunder() makes the thread index opaque to the optimiser from
 // there on, so the (cheap) index arithmetic is redone per sequence instead of being hoisted out of the loop into
 // hundreds of live registers.
@@ -57,11 +72,19 @@ __global__ __launch_bounds__(F* S::TPF) void k1_kernel(K1Params<T> p) {
 // two workgroups per CU is what keeps HBM busy while the other workgroup computes: ask the register
 // allocator for (2 * threads / 256) waves per SIMD
 // ABL bit 6 (64): pair-fused first two sub-passes (engine.h; a production option, not an ablation)
+// ABL bit 12 (4096, tuning): two virtual threads per physical thread (DevExecPair)
+template <class S, int F, int ABL> constexpr int k2_threads() { return (ABL & 4096) ? F * S::TPF / 2 : F * S::TPF; }
 template <class T, class S, int F, bool FIRST, bool SPLIT, int ABL = 0>
-__global__ __launch_bounds__(F* S::TPF, (F * S::TPF >= 512 ? 4 : 2)) void k2_kernel(K2Params<T> p) {
+__global__ __launch_bounds__((k2_threads<S, F, ABL>()), (k2_threads<S, F, ABL>() >= 512 ? 4 : 2)) void k2_kernel(K2Params<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    DevExec<T, regs_needed<S, SPLIT>()> ex;
-    k2_body<T, S, F, FIRST, SPLIT, ABL>(ex, p, (long long)blockIdx.x, smem);
+    if constexpr ((ABL & 4096) != 0) {
+        static_assert(F % 2 == 0 && !(ABL & 64), "pairs of adjacent columns");
+        DevExecPair<T, regs_needed<S, SPLIT>()> ex;
+        k2_body<T, S, F, FIRST, SPLIT, ABL>(ex, p, (long long)blockIdx.x, smem);
+    } else {
+        DevExec<T, regs_needed<S, SPLIT>()> ex;
+        k2_body<T, S, F, FIRST, SPLIT, ABL>(ex, p, (long long)blockIdx.x, smem);
+    }
 }
 
 template <class T, class S, int F, bool SPLIT, int STAGE>
@@ -121,13 +144,13 @@ template <class T, class S, int F, bool FIRST, bool SPLIT, int ABL = 0> KernelEn
     e.n = S::N;
     e.f = F;
     fill_sched<S>(e);
-    e.threads = F * S::TPF;
+    e.threads = k2_threads<S, F, ABL>();
     e.lds_bytes = k2_lds_bytes<T, S, F, SPLIT, ABL>();
     e.split = SPLIT;
     e.name = name;
     e.launch = [](const void* params, long long grid, void* stream) {
         void* args[] = {const_cast<void*>(params)};
-        (void)hipLaunchKernel((const void*)k2_kernel<T, S, F, FIRST, SPLIT, ABL>, dim3((unsigned)grid), dim3(F * S::TPF), args,
+        (void)hipLaunchKernel((const void*)k2_kernel<T, S, F, FIRST, SPLIT, ABL>, dim3((unsigned)grid), dim3(k2_threads<S, F, ABL>()), args,
                               k2_lds_bytes<T, S, F, SPLIT, ABL>(), (hipStream_t)stream);
     };
     e.prepare = []() -> int {

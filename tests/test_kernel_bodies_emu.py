@@ -680,6 +680,35 @@ def test_rader_register_handover(emu_planner, oracle, order):
         os.environ.pop("MI355_EMU_ORDER", None)
 
 
+@pytest.mark.parametrize("order", ["forward", "reverse"])
+def test_two_columns_per_lane_tiles(emu_planner, oracle, order):
+    """Tuning variants 50 - 53 of the column tiles (launch.h DevExecPair, kernels.h k2_body ABL bit 4096): two virtual threads --
+    adjacent columns of the same rows -- per physical thread, the even one moving both columns' rows as 16-byte accesses.  The
+    emulator runs the virtual threads as ordinary threads (their register arrays are adjacent exactly as on the device), so this
+    checks the schedules with 16 values per virtual thread, the separate load / store phases and their index arithmetic, in
+    both thread orders; the pairing itself is the four lines of DevExecPair."""
+    if order == "reverse":
+        os.environ["MI355_EMU_ORDER"] = "reverse"
+    try:
+        for variant, n, tag in (("50", 1 << 20, "1024, 64, 8, 8, 16"), ("51", 1 << 20, "1024, 64, 16, 8, 8"), ("52", 1 << 22, "2048, 128, 8, 16, 16"),
+                                ("53", 1 << 21, "2048, 128, 16, 16, 8")):
+            os.environ["MI355FFT_VARIANT"] = variant
+            planner = emu_planner(np.complex64)  # (a planner caches its plans per length: one per variant)
+            for d in (0, 1):
+                fft = planner.plan_fft(n, d)
+                assert fft.describe().count(tag) >= 1 and "abl4" in fft.describe(), (variant, fft.describe())
+                x = random_signal(2 * n, np.complex64, seed=int(variant))
+                y = x.copy()
+                fft.process(y)
+                assert rel_l2(y, numpy_fft(x, n, d == 1)) < 5e-6, (variant, d, fft.describe())
+                z = np.zeros_like(x)
+                fft.process_immutable_with_scratch(x, z, np.zeros(0, dtype=np.complex64))
+                assert np.array_equal(z, y), (variant, d, "immutable")
+    finally:
+        os.environ.pop("MI355FFT_VARIANT", None)
+        os.environ.pop("MI355_EMU_ORDER", None)
+
+
 def test_thread_order_independence(emu_planner, oracle):
     """The emulator runs the threads of a phase one after another, so a race between threads of one phase is invisible to it
     unless the order changes: MI355_EMU_ORDER=reverse runs every phase from the last thread to the first.  Results must not
