@@ -21,7 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--exhaustive", type=int, default=17000, help="every length up to here through AUTO (covers every whole-row kernel: the two-kernel Bluestein ends at 16384)")
     ap.add_argument("--asked-max", type=int, default=9000, help="every length up to here also through the three requested families")
-    ap.add_argument("--structured-max", type=int, default=1 << 24)
+    ap.add_argument("--structured-max", type=int, default=1 << 20, help="13-smooth lengths, primes with a smooth p - 1 and prime-tile composites up to here (2^24 takes most of an hour: the host builds a Rader table per large prime)")
     args = ap.parse_args()
     import numpy as np
 
