@@ -50,7 +50,8 @@ def main():
 
     sm = smooth13(args.structured_max)
     structured = sorted(v for v in sm if v > args.exhaustive)
-    structured += [1 << k for k in range(25, 31)]
+    structured += [v for v in (1 << k for k in range(10, 31)) if v > args.exhaustive and v not in structured]  # every power of two up to 2^30
+    structured += [v for v in (3 << 20, 5 << 20, 9 << 19, 3 << 22, 7 << 21) if v not in structured]                 # and a few large smooth lengths
     structured += sorted(p for p in (v + 1 for v in sm if v + 1 > args.exhaustive) if is_prime(p))
     # composites of two or three factors from the prime-tile range (a sample: every pair of tile primes)
     tile_primes = [p for p in range(37, 640) if is_prime(p)]
