@@ -220,7 +220,7 @@ MI_HD void k2_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
         // is the same thread; the emulator runs phases one after the other), the engine then applies the inter-pass factors
         // (K2Src skips its loads), and the later passes store both columns' outputs as 16 bytes the same way.
         constexpr int NREG = regs_needed<S, SPLIT>(), R0 = S::R[0], NB0 = S::nb(0), BPT0 = S::bpt(0), TPF = S::TPF;
-        static_assert(F % 2 == 0, "pairs of adjacent columns");
+        static_assert(F % 2 == 0 && sizeof(T) == 4, "pairs of adjacent columns; Complex<f32> only: a pair is one 16-byte access, the alignment the API guarantees");
         struct alignas(2 * sizeof(cx<T>)) cx2 {
             cx<T> a, b;
         };
