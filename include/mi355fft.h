@@ -184,6 +184,59 @@ int mi355fft_process_outofplace_dev(const mi355fft_plan* plan, void* input, void
 int mi355fft_process_immutable_dev(const mi355fft_plan* plan, const void* input, void* output, size_t batch,
                                    void* stream);
 
+/* ---- one plan, every GPU of the node: batch rows sharded across devices ----------------------------------------
+ * A batched call is `batch` independent transforms stored back to back -- the chunk loop of src/array_utils.rs:151-177
+ * (validate_and_iter) -- so the rows shard across devices with no collective in the data path: shard g of G owns the rows
+ *     [g * ceil(batch / G), min(batch, (g + 1) * ceil(batch / G)))                      (mi355fft_shard_rows)
+ * with its own replica of the (small) plan tables.  This is what lets the LITERAL drop-in,
+ * `Arc<dyn Fft<T>>::process(&mut [Complex<T>])` (src/lib.rs:195-255), use all eight GPUs of a node through an unchanged
+ * call site: one host thread + one staging pool per device, eight host links and eight HBM stacks instead of one
+ * (examples/concurrency.rs:9-30 is the reference's own multi-thread-over-one-plan pattern).
+ * `devices`: HIP device ordinals, n_devices >= 1; NULL / 0 = every visible gfx950 device.  An ordinal may appear more
+ * than once (each entry is one shard with its own replica and streams; `{0, 0}` exercises the whole path on one GPU).
+ * `options`: as mi355fft_plan_create_ex (NULL = the GPU planner decides); every replica is built from the same options.
+ * Thread safety as for a plan: any number of host threads may call mi355fft_multi_process_* on one object. */
+typedef struct mi355fft_multi_plan mi355fft_multi_plan;
+int mi355fft_multi_plan_create(size_t len, int direction, int precision, const mi355fft_plan_options* options,
+                               const int* devices, int n_devices, mi355fft_multi_plan** out_plan);
+int mi355fft_multi_plan_destroy(mi355fft_multi_plan* plan);
+int mi355fft_multi_plan_shards(const mi355fft_multi_plan* plan);            /* G */
+int mi355fft_multi_plan_device(const mi355fft_multi_plan* plan, int shard); /* device ordinal of shard g, -1 if out of range */
+/* The replica of shard g (len / direction / describe / workspace queries; owned by the multi-plan). */
+const mi355fft_plan* mi355fft_multi_plan_replica(const mi355fft_multi_plan* plan, int shard);
+/* The sharding law above: rows [*first_row, *first_row + *rows) of a batch of `batch` belong to shard g of G. */
+int mi355fft_shard_rows(size_t batch, int n_shards, int shard, size_t* first_row, size_t* rows);
+
+/* Host slices: the three trait methods (same validation order, messages and partial-chunk behaviour as the one-device
+ * entry points above).  The rows are split by mi355fft_shard_rows; every device stages, transforms and copies back its own
+ * rows concurrently (one worker thread per shard inside the library); the call returns when all rows are back. */
+int mi355fft_multi_process_inplace_host(const mi355fft_multi_plan* plan, void* buffer, size_t n_elems, void* scratch,
+                                        size_t scratch_elems);
+int mi355fft_multi_process_outofplace_host(const mi355fft_multi_plan* plan, void* input, size_t n_in, void* output,
+                                           size_t n_out, void* scratch, size_t scratch_elems);
+int mi355fft_multi_process_immutable_host(const mi355fft_multi_plan* plan, const void* input, size_t n_in, void* output,
+                                          size_t n_out, void* scratch, size_t scratch_elems);
+
+/* Device-resident shards (the measured multi-GPU path): buffers[g] points to shard g's rows -- mi355fft_shard_rows(batch,
+ * G, g) rows of `len` elements, back to back -- in the memory of device g (16-byte aligned; ignored when the shard is
+ * empty).  streams[g] is a hipStream_t of device g (streams == NULL or streams[g] == NULL: that device's default stream).
+ * Asynchronous: the call returns when every shard's kernels are enqueued; mi355fft_multi_synchronize waits for them. */
+int mi355fft_multi_process_inplace_dev(const mi355fft_multi_plan* plan, void* const* buffers, size_t batch,
+                                       void* const* streams);
+int mi355fft_multi_process_outofplace_dev(const mi355fft_multi_plan* plan, void* const* inputs, void* const* outputs,
+                                          size_t batch, void* const* streams);
+int mi355fft_multi_process_immutable_dev(const mi355fft_multi_plan* plan, const void* const* inputs, void* const* outputs,
+                                         size_t batch, void* const* streams);
+int mi355fft_multi_synchronize(const mi355fft_multi_plan* plan, void* const* streams);
+/* The optional edges when the whole batch lives on ONE device: peer copies (hipMemcpyPeerAsync over xGMI) of every shard's
+ * rows from / to `root_buffer` (batch * len elements on device `root_device`), enqueued on the shards' streams.  The data
+ * path itself has no collective; these are bounded by the root's links and are never part of a
+ * timed transform. */
+int mi355fft_multi_scatter_dev(const mi355fft_multi_plan* plan, const void* root_buffer, int root_device,
+                               void* const* buffers, size_t batch, void* const* streams);
+int mi355fft_multi_gather_dev(const mi355fft_multi_plan* plan, void* const* buffers, void* root_buffer, int root_device,
+                              size_t batch, void* const* streams);
+
 /* ---- measurement hooks (used by bench.py; not part of the reference surface) -----------------------------
  * Number of kernel launches one in-place transform of this plan issues, and their names. */
 int mi355fft_plan_num_kernels(const mi355fft_plan* plan);
@@ -196,6 +249,21 @@ int mi355fft_profile_inplace_dev(const mi355fft_plan* plan, void* buffer, size_t
  * pattern that reaches the chip's measured 6.2 - 6.3 TB/s): the data-movement ceiling bench.py quotes next to the 8 TB/s
  * spec.  Allocates and frees two scratch buffers of that size. */
 int mi355fft_measure_copy_ceiling(size_t bytes, double* gbps);
+/* Fused two-pass launches.  A two-pass power-of-two plan (2^16 .. 2^22 in Complex<f32>) can run BOTH column-tile passes in
+ * one launch: the second pass of transform g - lag runs beside the first pass of transform g, and the intermediate goes
+ * through a ring of a few transform-sized slots that stays in the Infinity Cache, so HBM sees one read and one write per
+ * transform instead of two (the reference's own structure, for comparison: Radix4 / MixedRadix sweep the whole buffer once
+ * per level, src/algorithm/radix4.rs:167-203).  The planner uses it where an on-device A/B measured a gain; this setter
+ * overrides that: -1 = the planner's choice (default), 0 = never, 1 = whenever a fused kernel exists for the plan.
+ * Batches with fewer transforms than the ring has slots always run as two launches.  Results are those of the two-launch
+ * plan up to the rounding of differently contracted multiply-adds (same kernel bodies). */
+int mi355fft_plan_set_fused(mi355fft_plan* plan, int mode);
+/* 1 when process_* calls of this plan currently use a fused launch (for a large enough batch), else 0. */
+int mi355fft_plan_is_fused(const mi355fft_plan* plan);
+/* Waits between the workgroups of a fused launch are bounded; a wait that gave up sets an
+ * error word instead of hanging the GPU.  This call synchronises `stream` and returns the word of the plan's most recent fused
+ * launch on that stream through *error_word (0 = every dependency was met in time; also 0 when the plan never ran fused). */
+int mi355fft_plan_fused_status(const mi355fft_plan* plan, void* stream, unsigned* error_word);
 /* Tunables (0 = library default): transforms per workspace chunk of the multi-pass path. */
 int mi355fft_plan_set_chunk_batch(mi355fft_plan* plan, size_t chunk_batch);
 /* Plan-owned HBM workspaces (one per stream the plan was used on, kept for reuse): bytes currently held, and a

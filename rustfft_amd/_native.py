@@ -16,7 +16,11 @@ EXPORTS = [
     "mi355fft_process_inplace_host", "mi355fft_process_outofplace_host", "mi355fft_process_immutable_host",
     "mi355fft_process_inplace_dev", "mi355fft_process_outofplace_dev", "mi355fft_process_immutable_dev",
     "mi355fft_plan_num_kernels", "mi355fft_plan_kernel_name", "mi355fft_profile_inplace_dev",
-    "mi355fft_measure_copy_ceiling", "mi355fft_plan_set_chunk_batch", "mi355fft_plan_workspace_bytes", "mi355fft_plan_trim_workspaces", "mi355fft_strerror", "mi355fft_last_error", "mi355fft_version",
+    "mi355fft_multi_plan_create", "mi355fft_multi_plan_destroy", "mi355fft_multi_plan_shards", "mi355fft_multi_plan_device", "mi355fft_multi_plan_replica", "mi355fft_shard_rows",
+    "mi355fft_multi_process_inplace_host", "mi355fft_multi_process_outofplace_host", "mi355fft_multi_process_immutable_host",
+    "mi355fft_multi_process_inplace_dev", "mi355fft_multi_process_outofplace_dev", "mi355fft_multi_process_immutable_dev",
+    "mi355fft_multi_synchronize", "mi355fft_multi_scatter_dev", "mi355fft_multi_gather_dev",
+    "mi355fft_measure_copy_ceiling", "mi355fft_plan_set_fused", "mi355fft_plan_is_fused", "mi355fft_plan_fused_status", "mi355fft_plan_set_chunk_batch", "mi355fft_plan_workspace_bytes", "mi355fft_plan_trim_workspaces", "mi355fft_strerror", "mi355fft_last_error", "mi355fft_version",
 ]
 
 
@@ -59,12 +63,32 @@ def bind(lib):
     lib.mi355fft_process_inplace_dev.argtypes = [vp, vp, sz, vp]
     lib.mi355fft_process_outofplace_dev.argtypes = [vp, vp, vp, sz, vp]
     lib.mi355fft_process_immutable_dev.argtypes = [vp, vp, vp, sz, vp]
+    pvp, pci = ctypes.POINTER(vp), ctypes.POINTER(ci)
+    lib.mi355fft_multi_plan_create.argtypes = [sz, ci, ci, ctypes.POINTER(PlanOptions), pci, ci, ctypes.POINTER(vp)]
+    lib.mi355fft_multi_plan_destroy.argtypes = [vp]
+    lib.mi355fft_multi_plan_shards.argtypes = [vp]
+    lib.mi355fft_multi_plan_device.argtypes = [vp, ci]
+    lib.mi355fft_multi_plan_replica.restype = vp
+    lib.mi355fft_multi_plan_replica.argtypes = [vp, ci]
+    lib.mi355fft_shard_rows.argtypes = [sz, ci, ci, ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    lib.mi355fft_multi_process_inplace_host.argtypes = [vp, vp, sz, vp, sz]
+    lib.mi355fft_multi_process_outofplace_host.argtypes = [vp, vp, sz, vp, sz, vp, sz]
+    lib.mi355fft_multi_process_immutable_host.argtypes = [vp, vp, sz, vp, sz, vp, sz]
+    lib.mi355fft_multi_process_inplace_dev.argtypes = [vp, pvp, sz, pvp]
+    lib.mi355fft_multi_process_outofplace_dev.argtypes = [vp, pvp, pvp, sz, pvp]
+    lib.mi355fft_multi_process_immutable_dev.argtypes = [vp, pvp, pvp, sz, pvp]
+    lib.mi355fft_multi_synchronize.argtypes = [vp, pvp]
+    lib.mi355fft_multi_scatter_dev.argtypes = [vp, vp, ci, pvp, sz, pvp]
+    lib.mi355fft_multi_gather_dev.argtypes = [vp, pvp, vp, ci, sz, pvp]
     lib.mi355fft_plan_num_kernels.argtypes = [vp]
     lib.mi355fft_plan_kernel_name.restype = ctypes.c_char_p
     lib.mi355fft_plan_kernel_name.argtypes = [vp, ci]
     lib.mi355fft_profile_inplace_dev.argtypes = [vp, vp, sz, vp, ci, ctypes.POINTER(ctypes.c_float), ci]
     lib.mi355fft_measure_copy_ceiling.argtypes = [sz, ctypes.POINTER(ctypes.c_double)]
     lib.mi355fft_plan_set_chunk_batch.argtypes = [vp, sz]
+    lib.mi355fft_plan_set_fused.argtypes = [vp, ci]
+    lib.mi355fft_plan_is_fused.argtypes = [vp]
+    lib.mi355fft_plan_fused_status.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_uint)]
     lib.mi355fft_plan_workspace_bytes.restype = sz
     lib.mi355fft_plan_workspace_bytes.argtypes = [vp]
     lib.mi355fft_plan_trim_workspaces.argtypes = [vp, ctypes.POINTER(sz)]

@@ -16,6 +16,9 @@ int h2d(void* d, const void* h, size_t bytes, void* stream);
 int d2h(void* h, const void* d, size_t bytes, void* stream);
 int d2d(void* dst, const void* src, size_t bytes, void* stream);
 int sync(void* stream);
+int memset_async(void* d, int value, size_t bytes, void* stream);
+// device-to-device copy between two devices (xGMI on an MI355X node), asynchronous on `stream` (a stream of the current device)
+int memcpy_peer(void* dst, int dst_device, const void* src, int src_device, size_t bytes, void* stream);
 int sync_device();                // drains every stream of the current device
 int check_launch();                // last launch error -> 0 / nonzero
 std::string last_error();
@@ -24,6 +27,8 @@ void event_destroy(void* e);
 void event_record(void* e, void* stream);
 float event_elapsed_ms(void* a, void* b);  // synchronises on b
 int event_sync(void* e);                   // blocks the calling thread until the event has completed
+int stream_wait_event(void* stream, void* e);  // work enqueued on `stream` after this call waits for the event's last record
+void* event_create_notiming();              // ordering-only event (cheaper to record / wait on than a timing event)
 void* stream_create();                     // non-blocking stream on the current device (the host-slice path's own streams)
 void stream_destroy(void* s);
 // read + write GB/s of the fastest plain copy this chip does (one float4 per thread, huge grid): the measured data-movement

@@ -48,6 +48,11 @@ int h2d(void* d, const void* h, size_t bytes, void* s) { return fail(hipMemcpyAs
 int d2h(void* h, const void* d, size_t bytes, void* s) { return fail(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)s)); }
 int d2d(void* dst, const void* src, size_t bytes, void* s) { return fail(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s)); }
 int sync(void* s) { return fail(hipStreamSynchronize((hipStream_t)s)); }
+int memset_async(void* d, int value, size_t bytes, void* s) { return fail(hipMemsetAsync(d, value, bytes, (hipStream_t)s)); }
+int memcpy_peer(void* dst, int dst_device, const void* src, int src_device, size_t bytes, void* s) {
+    if (dst_device == src_device) return fail(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
+    return fail(hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, (hipStream_t)s));
+}
 int sync_device() { return fail(hipDeviceSynchronize()); }
 int check_launch() { return fail(hipGetLastError()); }
 std::string last_error() { return g_err; }
@@ -65,6 +70,12 @@ float event_elapsed_ms(void* a, void* b) {
     return ms;
 }
 int event_sync(void* e) { return fail(hipEventSynchronize((hipEvent_t)e)); }
+int stream_wait_event(void* s, void* e) { return fail(hipStreamWaitEvent((hipStream_t)s, (hipEvent_t)e, 0)); }
+void* event_create_notiming() {
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+    return (void*)e;
+}
 void* stream_create() {
     hipStream_t s;
     if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;

@@ -1,6 +1,9 @@
 // extern "C" surface declared in include/mi355fft.h.
 #include <algorithm>
 #include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -62,7 +65,10 @@ void* stage(Workspace& w, size_t bytes) {
 // One upload and one download at a time per process: concurrent blocking pageable copies in the SAME direction thrash (four
 // threads at once: 29 - 37 GB/s of aggregate payload against 45 for one caller; tools/hostpath_bench.py), so the chunk copies of
 // concurrent host-slice calls take turns per direction while their kernels and the opposite direction overlap.
-std::mutex g_upload_turn, g_download_turn;
+// (per DEVICE: every GPU has its own host link, so the shards of a multi-device call copy concurrently)
+constexpr int kMaxTurnDevices = 64;
+std::mutex g_upload_turn[kMaxTurnDevices], g_download_turn[kMaxTurnDevices];
+inline int turn_index(int device) { return device >= 0 ? device % kMaxTurnDevices : 0; }
 
 // A staging context of the plan's pool for the duration of one host-slice call.
 struct HostLease {
@@ -95,7 +101,7 @@ struct HostLease {
 // box, tools/hostprobe: blocking pageable copies 56 GB/s up, 52 - 56 down, 27 - 28 GB/s of payload per round trip when one
 // follows the other; both directions at once 33 - 37 GB/s per direction, whether the caller's pages are registered or not --
 // the ceiling of this path; a CPU memcpy through pinned staging buffers reaches 15).
-int process_host(const mi355fft_plan* cplan, const void* in, size_t n_in, void* out, size_t n_out, size_t scratch_elems, int mode) {
+int process_host_impl(const mi355fft_plan* cplan, const void* in, size_t n_in, void* out, size_t n_out, size_t scratch_elems, int mode) {
     if (!cplan) return set_err(MI355FFT_ERR_INVALID_ARG, "null plan");
     Plan& plan = const_cast<Plan&>(cplan->p);
     const size_t len = plan.len;
@@ -145,7 +151,7 @@ int process_host(const mi355fft_plan* cplan, const void* in, size_t n_in, void* 
                 }
                 const size_t r0 = c * rows_per_chunk, rows = std::min(rows_per_chunk, batch - r0), slot = (c % nslots) * slot_bytes;
                 int rc = backend::event_sync(done[c]);
-                std::unique_lock<std::mutex> turn(g_download_turn);
+                std::unique_lock<std::mutex> turn(g_download_turn[turn_index(device)]);
                 if (!rc) rc = backend::d2h((char*)out + r0 * row, d_out + slot, rows * row, cx.stream_b);
                 // the reference's out-of-place variant leaves `input` in an unspecified state; mirror the device buffer back so
                 // host and device callers observe the same (clobbered) contents
@@ -172,7 +178,7 @@ int process_host(const mi355fft_plan* cplan, const void* in, size_t n_in, void* 
                 if (rc_dl != MI355FFT_OK) break;
             }
             {
-                std::lock_guard<std::mutex> turn(g_upload_turn);
+                std::lock_guard<std::mutex> turn(g_upload_turn[turn_index(device)]);
                 if (backend::h2d(d_in + slot, (const char*)in + r0 * row, rows * row, cx.stream_a) || backend::sync(cx.stream_a)) {
                     rc_main = hip_err(MI355FFT_ERR_HIP);
                     break;
@@ -210,6 +216,17 @@ int process_host(const mi355fft_plan* cplan, const void* in, size_t n_in, void* 
     // a trailing partial chunk is reported after the complete chunks were transformed (array_utils.rs:164-176)
     if (rem != 0) return validation_error(len, n_in, n_out, false);
     return MI355FFT_OK;
+}
+
+// std::thread / std::vector construction can throw; nothing may unwind through the extern "C" boundary
+int process_host(const mi355fft_plan* cplan, const void* in, size_t n_in, void* out, size_t n_out, size_t scratch_elems, int mode) {
+    try {
+        return process_host_impl(cplan, in, n_in, out, n_out, scratch_elems, mode);
+    } catch (const std::bad_alloc&) {
+        return set_err(MI355FFT_ERR_OUT_OF_MEMORY, "host allocation failed in the host-slice pipeline");
+    } catch (const std::exception& e) {
+        return set_err(MI355FFT_ERR_HIP, std::string("host-slice pipeline: ") + e.what());
+    }
 }
 
 struct EventTracer : Tracer {
@@ -398,6 +415,25 @@ int mi355fft_measure_copy_ceiling(size_t bytes, double* gbps) {
     *gbps = backend::copy_ceiling_gbps(bytes);
     return *gbps > 0 ? MI355FFT_OK : set_err(MI355FFT_ERR_HIP, "copy measurement failed");
 }
+int mi355fft_plan_set_fused(mi355fft_plan* plan, int mode) {
+    if (!plan || mode < -1 || mode > 1) return set_err(MI355FFT_ERR_INVALID_ARG, "bad fused mode");
+    Plan& p = plan->p;
+    p.fuse_on = p.fused && (mode == 1 || (mode == -1 && p.fused->aux == 1));
+    return MI355FFT_OK;
+}
+int mi355fft_plan_is_fused(const mi355fft_plan* plan) { return plan && plan->p.fuse_on && plan->p.fused ? 1 : 0; }
+int mi355fft_plan_fused_status(const mi355fft_plan* plan, void* stream, unsigned* error_word) {
+    if (!plan || !error_word) return set_err(MI355FFT_ERR_INVALID_ARG, "null argument");
+    *error_word = 0;
+    Plan& p = const_cast<Plan&>(plan->p);
+    DeviceGuard dev(p.device);
+    StreamSlot& slot = p.slot_for(stream);
+    std::lock_guard<std::mutex> g(slot.launch_mutex);
+    if (!slot.pipe.ctrl) return MI355FFT_OK;
+    if (backend::sync(stream) || backend::d2h(error_word, (const char*)slot.pipe.ctrl + sizeof(unsigned), sizeof(unsigned), stream) || backend::sync(stream))
+        return hip_err(MI355FFT_ERR_HIP);
+    return MI355FFT_OK;
+}
 int mi355fft_plan_set_chunk_batch(mi355fft_plan* plan, size_t chunk_batch) {
     if (!plan) return set_err(MI355FFT_ERR_INVALID_ARG, "null plan");
     plan->p.chunk_batch = chunk_batch;
@@ -429,4 +465,268 @@ const char* mi355fft_strerror(int status) {
 }
 const char* mi355fft_last_error(void) { return g_last_error.c_str(); }
 const char* mi355fft_version(void) { return "mi355fft 0.1 (gfx950)"; }
+}  // extern "C"
+
+// ---- one plan over several devices: batch rows sharded across GPUs (include/mi355fft.h, "one plan, every GPU of the node") ----
+// The reference's batch loop (src/array_utils.rs:151-177) is the shard axis: rows [g ceil(batch / G), (g + 1) ceil(batch / G))
+// go to shard g.  Every shard has its own replica plan (tables on its device), its own staging pool and streams, and a
+// persistent worker thread bound to its device; a call hands every worker its rows and waits -- no collective, no data of one
+// shard ever touches another device.  Only the optional scatter / gather edges move rows between devices (peer copies).
+namespace {
+struct ShardWorker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    bool stop = false;
+    explicit ShardWorker(int device) {
+        th = std::thread([this, device] {
+            backend::set_device(device);
+            for (;;) {
+                std::function<void()> job;
+                {
+                    std::unique_lock<std::mutex> lk(m);
+                    cv.wait(lk, [&] { return stop || !q.empty(); });
+                    if (q.empty()) return;
+                    job = std::move(q.front());
+                    q.pop_front();
+                }
+                job();
+            }
+        });
+    }
+    void submit(std::function<void()> job) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            q.push_back(std::move(job));
+        }
+        cv.notify_one();
+    }
+    ~ShardWorker() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv.notify_one();
+        if (th.joinable()) th.join();
+    }
+};
+// completion of one multi-device call: every shard reports its status and message
+struct ShardJoin {
+    std::mutex m;
+    std::condition_variable cv;
+    int pending;
+    int rc = MI355FFT_OK;
+    std::string msg;
+    explicit ShardJoin(int n) : pending(n) {}
+    void done(int status) {
+        std::lock_guard<std::mutex> lk(m);
+        if (status != MI355FFT_OK && rc == MI355FFT_OK) {
+            rc = status;
+            msg = g_last_error;  // the worker thread's message
+        }
+        if (--pending == 0) cv.notify_all();
+    }
+    int wait() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return pending == 0; });
+        if (rc != MI355FFT_OK) g_last_error = msg;
+        return rc;
+    }
+};
+void shard_rows(size_t batch, int n_shards, int shard, size_t* first, size_t* rows) {
+    const size_t per = n_shards > 0 ? (batch + (size_t)n_shards - 1) / (size_t)n_shards : batch;
+    const size_t lo = std::min(batch, (size_t)shard * per), hi = std::min(batch, ((size_t)shard + 1) * per);
+    *first = lo;
+    *rows = hi - lo;
+}
+}  // namespace
+
+struct mi355fft_multi_plan {
+    std::vector<int> devices;
+    std::vector<mi355fft_plan*> replicas;
+    std::vector<std::unique_ptr<ShardWorker>> workers;
+    size_t len = 0;
+    int prec = 32;
+    ~mi355fft_multi_plan() {
+        workers.clear();  // joins the threads (queued jobs run first)
+        for (size_t g = 0; g < replicas.size(); ++g) {
+            DeviceGuard dev(devices[g]);
+            delete replicas[g];
+        }
+    }
+};
+
+namespace {
+// runs fn(shard) on every shard's worker and returns the first failure
+template <class Fn> int on_all_shards(const mi355fft_multi_plan* mp, Fn fn) {
+    const int G = (int)mp->replicas.size();
+    ShardJoin join(G);
+    for (int g = 0; g < G; ++g)
+        mp->workers[g]->submit([&join, &fn, g] {
+            int rc;
+            try {
+                rc = fn(g);
+            } catch (const std::bad_alloc&) {
+                rc = set_err(MI355FFT_ERR_OUT_OF_MEMORY, "host allocation failed in a shard worker");
+            } catch (const std::exception& e) {
+                rc = set_err(MI355FFT_ERR_HIP, std::string("shard worker: ") + e.what());
+            }
+            join.done(rc);
+        });
+    return join.wait();
+}
+int multi_process_host(const mi355fft_multi_plan* mp, const void* in, size_t n_in, void* out, size_t n_out, int mode) {
+    if (!mp) return set_err(MI355FFT_ERR_INVALID_ARG, "null plan");
+    const size_t len = mp->len;
+    if (len == 0) return MI355FFT_OK;  // fft_helper.rs:16-18
+    if (mode != 0 && n_in != n_out) return validation_error(len, n_in, n_out, true);
+    const size_t batch = n_in / len, rem = n_in % len, esz = mp->prec == 32 ? 8 : 16;
+    if (batch > 0) {
+        if (!in || !out) return set_err(MI355FFT_ERR_INVALID_ARG, "null buffer");
+        const int G = (int)mp->replicas.size();
+        int rc = on_all_shards(mp, [&](int g) -> int {
+            size_t first, rows;
+            shard_rows(batch, G, g, &first, &rows);
+            if (rows == 0) return MI355FFT_OK;
+            const char* sin = (const char*)in + first * len * esz;
+            char* sout = (char*)out + first * len * esz;
+            return process_host(mp->replicas[g], sin, rows * len, sout, rows * len, 0, mode);
+        });
+        if (rc) return rc;
+    }
+    // a trailing partial chunk is reported after the complete chunks were transformed (array_utils.rs:164-176)
+    if (rem != 0) return validation_error(len, n_in, n_out, false);
+    return MI355FFT_OK;
+}
+int multi_process_dev(const mi355fft_multi_plan* mp, const void* const* in, void* const* out, size_t batch, void* const* streams, int mode) {
+    if (!mp) return set_err(MI355FFT_ERR_INVALID_ARG, "null plan");
+    if (batch == 0 || mp->len == 0) return MI355FFT_OK;
+    if (!in || !out) return set_err(MI355FFT_ERR_INVALID_ARG, "null shard buffer array");
+    const int G = (int)mp->replicas.size();
+    for (int g = 0; g < G; ++g) {
+        size_t first, rows;
+        shard_rows(batch, G, g, &first, &rows);
+        if (rows && (!in[g] || !out[g])) return set_err(MI355FFT_ERR_INVALID_ARG, "null device buffer for a non-empty shard");
+    }
+    // the shards' launch sequences are enqueued concurrently (a fused or chunked plan issues many launches per call)
+    return on_all_shards(mp, [&](int g) -> int {
+        size_t first, rows;
+        shard_rows(batch, G, g, &first, &rows);
+        if (rows == 0) return MI355FFT_OK;
+        const int m = (mode != 0 && in[g] == out[g]) ? 0 : mode;
+        int rc = execute(mp->replicas[g]->p, in[g], out[g], rows, streams ? streams[g] : nullptr, m, nullptr);
+        if (rc) return rc == MI355FFT_ERR_HIP ? hip_err(rc) : set_err(rc, "execution failed");
+        return MI355FFT_OK;
+    });
+}
+int multi_edge(const mi355fft_multi_plan* mp, void* const* buffers, void* root, int root_device, size_t batch, void* const* streams, bool scatter) {
+    if (!mp) return set_err(MI355FFT_ERR_INVALID_ARG, "null plan");
+    if (batch == 0 || mp->len == 0) return MI355FFT_OK;
+    if (!buffers || !root) return set_err(MI355FFT_ERR_INVALID_ARG, "null buffer");
+    const int G = (int)mp->replicas.size();
+    const size_t row = mp->len * (mp->prec == 32 ? 8 : 16);
+    return on_all_shards(mp, [&](int g) -> int {
+        size_t first, rows;
+        shard_rows(batch, G, g, &first, &rows);
+        if (rows == 0) return MI355FFT_OK;
+        if (!buffers[g]) return set_err(MI355FFT_ERR_INVALID_ARG, "null device buffer for a non-empty shard");
+        char* r = (char*)root + first * row;
+        void* st = streams ? streams[g] : nullptr;
+        const int rc = scatter ? backend::memcpy_peer(buffers[g], mp->devices[g], r, root_device, rows * row, st)
+                               : backend::memcpy_peer(r, root_device, buffers[g], mp->devices[g], rows * row, st);
+        return rc ? hip_err(MI355FFT_ERR_HIP) : MI355FFT_OK;
+    });
+}
+}  // namespace
+
+extern "C" {
+int mi355fft_shard_rows(size_t batch, int n_shards, int shard, size_t* first_row, size_t* rows) {
+    if (n_shards < 1 || shard < 0 || shard >= n_shards || !first_row || !rows) return set_err(MI355FFT_ERR_INVALID_ARG, "bad shard arguments");
+    shard_rows(batch, n_shards, shard, first_row, rows);
+    return MI355FFT_OK;
+}
+int mi355fft_multi_plan_create(size_t len, int direction, int precision, const mi355fft_plan_options* options, const int* devices, int n_devices,
+                               mi355fft_multi_plan** out_plan) {
+    if (!out_plan) return set_err(MI355FFT_ERR_INVALID_ARG, "out_plan is null");
+    *out_plan = nullptr;
+    if (n_devices < 0 || (n_devices > 0 && !devices)) return set_err(MI355FFT_ERR_INVALID_ARG, "bad device list");
+    if (int rc = ensure_init()) return rc;
+    const int visible = backend::device_count();
+    std::vector<int> devs;
+    if (n_devices == 0)
+        for (int d = 0; d < visible; ++d) devs.push_back(d);
+    else
+        devs.assign(devices, devices + n_devices);
+    for (int d : devs)
+        if (d < 0 || d >= visible) return set_err(MI355FFT_ERR_INVALID_ARG, "device ordinal out of range");
+    std::unique_ptr<mi355fft_multi_plan> mp;
+    try {
+        mp.reset(new mi355fft_multi_plan());
+        mp->len = len;
+        mp->prec = precision;
+        mp->devices = devs;
+        const int prev = backend::current_device();
+        int rc = MI355FFT_OK;
+        for (int d : devs) {  // a replica is bound to the device current at its creation
+            mi355fft_plan* r = nullptr;
+            if (backend::set_device(d)) {
+                rc = hip_err(MI355FFT_ERR_HIP);
+                break;
+            }
+            rc = mi355fft_plan_create_ex(len, direction, precision, options, &r);
+            if (rc) break;
+            mp->replicas.push_back(r);
+        }
+        if (prev >= 0) backend::set_device(prev);
+        if (rc) {
+            mp->devices.resize(mp->replicas.size());
+            return rc;  // the message of the failing replica is in g_last_error
+        }
+        for (int d : devs) mp->workers.emplace_back(new ShardWorker(d));
+    } catch (const std::exception& e) {
+        return set_err(MI355FFT_ERR_OUT_OF_MEMORY, std::string("multi-plan construction: ") + e.what());
+    }
+    *out_plan = mp.release();
+    return MI355FFT_OK;
+}
+int mi355fft_multi_plan_destroy(mi355fft_multi_plan* plan) {
+    delete plan;
+    return MI355FFT_OK;
+}
+int mi355fft_multi_plan_shards(const mi355fft_multi_plan* plan) { return plan ? (int)plan->replicas.size() : 0; }
+int mi355fft_multi_plan_device(const mi355fft_multi_plan* plan, int shard) {
+    return (plan && shard >= 0 && shard < (int)plan->devices.size()) ? plan->devices[shard] : -1;
+}
+const mi355fft_plan* mi355fft_multi_plan_replica(const mi355fft_multi_plan* plan, int shard) {
+    return (plan && shard >= 0 && shard < (int)plan->replicas.size()) ? plan->replicas[shard] : nullptr;
+}
+int mi355fft_multi_process_inplace_host(const mi355fft_multi_plan* plan, void* buffer, size_t n_elems, void*, size_t) {
+    return multi_process_host(plan, buffer, n_elems, buffer, n_elems, 0);
+}
+int mi355fft_multi_process_outofplace_host(const mi355fft_multi_plan* plan, void* input, size_t n_in, void* output, size_t n_out, void*, size_t) {
+    return multi_process_host(plan, input, n_in, output, n_out, 1);
+}
+int mi355fft_multi_process_immutable_host(const mi355fft_multi_plan* plan, const void* input, size_t n_in, void* output, size_t n_out, void*, size_t) {
+    return multi_process_host(plan, input, n_in, output, n_out, 2);
+}
+int mi355fft_multi_process_inplace_dev(const mi355fft_multi_plan* plan, void* const* buffers, size_t batch, void* const* streams) {
+    return multi_process_dev(plan, (const void* const*)buffers, buffers, batch, streams, 0);
+}
+int mi355fft_multi_process_outofplace_dev(const mi355fft_multi_plan* plan, void* const* inputs, void* const* outputs, size_t batch, void* const* streams) {
+    return multi_process_dev(plan, (const void* const*)inputs, outputs, batch, streams, 1);
+}
+int mi355fft_multi_process_immutable_dev(const mi355fft_multi_plan* plan, const void* const* inputs, void* const* outputs, size_t batch, void* const* streams) {
+    return multi_process_dev(plan, inputs, outputs, batch, streams, 2);
+}
+int mi355fft_multi_synchronize(const mi355fft_multi_plan* plan, void* const* streams) {
+    if (!plan) return set_err(MI355FFT_ERR_INVALID_ARG, "null plan");
+    return on_all_shards(plan, [&](int g) -> int { return backend::sync(streams ? streams[g] : nullptr) ? hip_err(MI355FFT_ERR_HIP) : MI355FFT_OK; });
+}
+int mi355fft_multi_scatter_dev(const mi355fft_multi_plan* plan, const void* root_buffer, int root_device, void* const* buffers, size_t batch, void* const* streams) {
+    return multi_edge(plan, buffers, const_cast<void*>(root_buffer), root_device, batch, streams, true);
+}
+int mi355fft_multi_gather_dev(const mi355fft_multi_plan* plan, void* const* buffers, void* root_buffer, int root_device, size_t batch, void* const* streams) {
+    return multi_edge(plan, buffers, root_buffer, root_device, batch, streams, false);
+}
 }  // extern "C"

@@ -22,6 +22,14 @@
 #define MI_SCHED_FENCE() ((void)0)
 #endif
 
+// A value the code knows to be workgroup-uniform although the compiler cannot prove it (the result of a division expanded into
+// vector instructions, a ticket read from LDS): v_readfirstlane moves it to an SGPR, and so everything derived from it.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MI_UNIFORM(x) ((unsigned)__builtin_amdgcn_readfirstlane((int)(x)))
+#else
+#define MI_UNIFORM(x) ((unsigned)(x))
+#endif
+
 namespace mi355 {
 
 template <class T> struct cx {
@@ -98,6 +106,48 @@ template <class T> MI_HD void st_nt(cx<T>* p, cx<T> v) {
     t.x = v.re;
     t.y = v.im;
     __builtin_nontemporal_store(t, (vec2*)p);
+#else
+    *p = v;
+#endif
+}
+
+// Agent-scope (device-coherent) accesses for data that another workgroup produces or consumes inside ONE launch (the fused
+// two-pass kernel's ring): relaxed agent-scope atomics lower to global_load / global_store ... sc1 -- the load is served past
+// this CU's L1 (which no other CU's store ever refreshes), the store is written through the XCD's L2 (whose dirty lines no
+// other XCD can see) -- so neither a release fence (buffer_wbl2: the whole L2 writes back) nor an acquire fence (buffer_inv:
+// the whole L1 is invalidated) is needed per tile.  Plain accesses on the host emulator.
+template <class T> MI_HD cx<T> ld_agent(const cx<T>* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (sizeof(T) == 4) {
+        const unsigned long long u = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cx<T> v;
+        __builtin_memcpy(&v, &u, 8);
+        return v;
+    } else {
+        const unsigned long long a = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long b = __hip_atomic_load((const unsigned long long*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cx<T> v;
+        __builtin_memcpy(&v.re, &a, 8);
+        __builtin_memcpy(&v.im, &b, 8);
+        return v;
+    }
+#else
+    return *p;
+#endif
+}
+template <class T> MI_HD void st_agent(cx<T>* p, cx<T> v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (sizeof(T) == 4) {
+        unsigned long long u;
+        __builtin_memcpy(&u, &v, 8);
+        __hip_atomic_store((unsigned long long*)p, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        unsigned long long a, b;
+        __builtin_memcpy(&a, &v.re, 8);
+        __builtin_memcpy(&b, &v.im, 8);
+        __hip_atomic_store((unsigned long long*)p, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((unsigned long long*)p + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 #else
     *p = v;
 #endif

@@ -119,7 +119,7 @@ constexpr int k2_pitch_mod(int f) { return f < 32 ? 32 / f : 1; }
 template <int ABL, int NP> constexpr int k2_twl() {
     return (ABL & 128) ? twl_all(NP) : (ABL & 1024) ? 2 : (ABL & 2048) ? (1 << (NP - 1)) : 0;
 }
-template <class T, bool FIRST, int ABL = 0, int F_ = 0> struct K2Src {
+template <class T, bool FIRST, int ABL = 0, int F_ = 0, int RING = 0> struct K2Src {
     static constexpr bool kLoadsAll = true;
     const cx<T>* in;  // no restrict: the in-place last pass reads and writes the caller's buffer
     unsigned M, b0, bmod0;
@@ -139,7 +139,9 @@ template <class T, bool FIRST, int ABL = 0, int F_ = 0> struct K2Src {
                 static_for<0, R>([&](auto K_) {
                     constexpr int k = K_;
                     const unsigned row = (unsigned)(u + m * TPF + k * NB);
-                    if constexpr ((ABL & 16) != 0)
+                    if constexpr ((RING & 2) != 0)
+                        v[m * R + k] = ld_agent(in + (col + row * M));  // fused kernel: the ring another workgroup wrote in this launch
+                    else if constexpr ((ABL & 16) != 0)
                         v[m * R + k] = ld_nt(in + (col + row * M));
                     else
                         v[m * R + k] = in[col + row * M];
@@ -174,39 +176,26 @@ template <class T, bool FIRST, int ABL = 0, int F_ = 0> struct K2Src {
     }
 };
 
-template <class T, class S, int F, bool FIRST, bool SPLIT, int ABL = 0, class X>
-MI_HD void k2_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
+// The tile of a power-of-two column-tile pass: transform g's rows at `in` / `out`, columns [tile F, (tile + 1) F).  k2_body maps a
+// workgroup index to (g, tile) for the one-pass-per-launch kernels, k2f_body (below) for the fused two-pass kernel.
+// RING (fused kernel): bit 0 = `out` is the ring: agent-scope stores; bit 1 = `in` is the ring: agent-scope loads (cx.h)
+template <class T, class S, int F, bool FIRST, bool SPLIT, int ABL = 0, int RING = 0, class X>
+MI_HD void k2_tile(X& ex, const K2Params<T>& p, const cx<T>* in, cx<T>* out, unsigned tile, void* lds) {
     constexpr int R = S::N;
-    // XCD-aware tile order.  Workgroup b is dispatched to XCD b % 8 (MI355X_MICROARCH.md, observed, used for speed
-    // only).  Within every aligned group of 8 << xq consecutive workgroups (all tiles of one transform), XCD x takes the
-    // tiles whose index has x in bits [xp, xp + 3): each XCD then streams runs of 2^xp ADJACENT tiles, and its requests
-    // spread over the address bits that select L2 / memory channels instead of sharing them.  Measured with the tile
-    // skeleton (tools/membench/skel.hip, 1024 x 16 tiles): identity order 5.1 / 4.9 TB/s (first / later pass shape),
-    // x at address bits 9-11 5.6 / 5.5.  For tiles narrower than a 128-byte line this also keeps the tiles that share
-    // a line on one XCD back to back (one L2 fetches the line once).
-    if (p.xq > 0) {
-        const int r = (int)(block & ((8LL << p.xq) - 1)), x = r & 7, i = r >> 3;
-        const int t = ((i >> p.xp) << (p.xp + 3)) | (x << p.xp) | (i & ((1 << p.xp) - 1));
-        block += t - r;
-    }
-    // M / F and S are powers of two for these plans: shifts, not 64-bit divisions (a 64-bit division is ~150 dependent
-    // scalar instructions in front of the first load of the workgroup)
-    const long long g = block >> p.tiles_shift;
-    const unsigned tile = (unsigned)(block & ((1LL << p.tiles_shift) - 1));
     const unsigned b0 = tile * (unsigned)F;
-    const cx<T>* in = p.in + g * p.n;
-    cx<T>* out = p.out + g * p.n;
     const unsigned M = (unsigned)p.m, s32 = (unsigned)p.s;
     const T sgn_out = p.sgn_out;
     // a tile never straddles a multiple of S (F | S whenever S > 1), so B div S is tile-uniform
     const unsigned bdiv = FIRST ? 0u : (b0 >> p.s_shift);
     const unsigned bmod0 = FIRST ? 0u : (b0 & (s32 - 1u));
     const unsigned obase = bdiv * s32 * (unsigned)R + bmod0;
-    K2Src<T, FIRST, ABL, F> src{in, M, b0, bmod0, p.sgn_in, p.tlo, p.thi, p.hshift, p.lmask};
+    K2Src<T, FIRST, ABL, F, RING> src{in, M, b0, bmod0, p.sgn_in, p.tlo, p.thi, p.hshift, p.lmask};
     auto dst = [=](int f, int k, cx<T> x) {
         x.im *= sgn_out;
         cx<T>* o = FIRST ? out + ((b0 + (unsigned)f) * (unsigned)R + (unsigned)k) : out + (obase + (unsigned)f + (unsigned)k * s32);
-        if constexpr ((ABL & 32) != 0)
+        if constexpr ((RING & 1) != 0)
+            st_agent(o, x);
+        else if constexpr ((ABL & 32) != 0)
             st_nt(o, x);
         else
             *o = x;
@@ -268,6 +257,66 @@ MI_HD void k2_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     } else {
         wg_fft<T, S, F, (ABL & 64) ? MAP_FFP : MAP_FF, FIRST ? MAP_EF : MAP_FF, SPLIT, false, k2_pitch_mod(F), (ABL & 15), -1, false, k2_twl<ABL, S::NP>()>(ex, lds, p.tw, src, dst);
     }
+}
+template <class T, class S, int F, bool FIRST, bool SPLIT, int ABL = 0, class X>
+MI_HD void k2_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
+    // XCD-aware tile order.  Workgroup b is dispatched to XCD b % 8 (MI355X_MICROARCH.md, observed, used for speed
+    // only).  Within every aligned group of 8 << xq consecutive workgroups (all tiles of one transform), XCD x takes the
+    // tiles whose index has x in bits [xp, xp + 3): each XCD then streams runs of 2^xp ADJACENT tiles, and its requests
+    // spread over the address bits that select L2 / memory channels instead of sharing them.  Measured with the tile
+    // skeleton (tools/membench/skel.hip, 1024 x 16 tiles): identity order 5.1 / 4.9 TB/s (first / later pass shape),
+    // x at address bits 9-11 5.6 / 5.5.  For tiles narrower than a 128-byte line this also keeps the tiles that share
+    // a line on one XCD back to back (one L2 fetches the line once).
+    if (p.xq > 0) {
+        const int r = (int)(block & ((8LL << p.xq) - 1)), x = r & 7, i = r >> 3;
+        const int t = ((i >> p.xp) << (p.xp + 3)) | (x << p.xp) | (i & ((1 << p.xp) - 1));
+        block += t - r;
+    }
+    // M / F and S are powers of two for these plans: shifts, not 64-bit divisions (a 64-bit division is ~150 dependent
+    // scalar instructions in front of the first load of the workgroup)
+    const long long g = block >> p.tiles_shift;
+    const unsigned tile = (unsigned)(block & ((1LL << p.tiles_shift) - 1));
+    k2_tile<T, S, F, FIRST, SPLIT, ABL, 0>(ex, p, p.in + g * p.n, p.out + g * p.n, tile, lds);
+}
+// ---- fused two-pass kernel: work-item decoding (shared by the gfx950 kernel and the host emulator) ------------------------
+struct K2FItem {
+    int pass;        // 0 / 1; -1: nothing to do (index past the end)
+    long long g;     // transform
+    unsigned tile;   // tile within the transform, XCD-aware order applied
+    unsigned slot;   // ring slot g % ns
+    unsigned use;    // g / ns: how many times the slot has been used before
+};
+// Steps of t0 + t1 items.  Within a step the items go in groups of eight per pass -- items [16 q, 16 q + 8) are first-pass tiles,
+// [16 q + 8, 16 q + 16) second-pass tiles (when t0 == t1 and both are multiples of 8; otherwise first-pass tiles, then
+// second-pass tiles) -- so that, with workgroup b on XCD b % 8, tile slot i of either pass runs on XCD i % 8 exactly as in the
+// one-pass kernels and the same XCD-aware tile permutation (K2Params::xp / xq) applies.
+template <class T> MI_HD K2FItem k2f_decode(const K2FusedParams<T>& fp, long long w) {
+    // 32-bit arithmetic (the grid is below 2^31); the quotients are workgroup-uniform
+    const unsigned t0 = (unsigned)fp.tiles[0], t1 = (unsigned)fp.tiles[1], per = t0 + t1, w32 = (unsigned)w;
+    const unsigned s = MI_UNIFORM(w32 / per), r = w32 - s * per;
+    K2FItem it{};
+    unsigned i;
+    if (t0 == t1 && (t0 & 7u) == 0) {
+        it.pass = (int)((r >> 3) & 1u);
+        i = ((r >> 4) << 3) | (r & 7u);
+    } else {
+        it.pass = r < t0 ? 0 : 1;
+        i = it.pass ? r - t0 : r;
+    }
+    it.g = it.pass ? (long long)s - fp.lag : (long long)s;
+    if (it.g < 0 || it.g >= fp.batch) {
+        it.pass = -1;
+        return it;
+    }
+    const K2Params<T>& p = fp.pass[it.pass];
+    if (p.xq > 0) {  // as k2_body: XCD id at tile-index bits [xp, xp + 3) within aligned groups of 8 << xq tiles
+        const unsigned rr = i & ((8u << p.xq) - 1u), x = rr & 7u, j = rr >> 3;
+        i += (((j >> p.xp) << (p.xp + 3)) | (x << p.xp) | (j & ((1u << p.xp) - 1u))) - rr;
+    }
+    it.tile = i;
+    it.use = MI_UNIFORM((unsigned)it.g / (unsigned)fp.ns);
+    it.slot = (unsigned)it.g - it.use * (unsigned)fp.ns;
+    return it;
 }
 // LDS bytes of a column-tile workgroup: the exchange buffer + the staged twiddle tables
 template <class T, class S, int F, bool SPLIT, int ABL> constexpr size_t k2_lds_bytes() {

@@ -54,6 +54,9 @@ void register_k2_f32(std::vector<KernelEntry>& reg) {
     MI_K2ABL(51, 4224, float, 32, 16, true, 1024, 64, 16, 8, 8);
     MI_K2ABL(52, 4096, float, 32, 16, true, 2048, 128, 8, 16, 16);
     MI_K2ABL(53, 4096, float, 32, 16, true, 2048, 128, 16, 16, 8);
+    // tuning 60: PERSISTENT workgroups (ABL bit 8192) for the one-workgroup-per-CU 2048-row later tile and, for comparison, the 1024-row tiles
+    MI_K2ABL(60, 8192, float, 32, 16, true, 2048, 64, 8, 16, 16);
+    MI_K2ABL(60, 8320, float, 32, 16, true, 1024, 32, 8, 8, 16);
     MI_K2V(10, float, 32, 16, true, 1024, 32, 32, 32);     // tuning: two radix-32 sub-passes, one exchange (the later pass spills)
     MI_K2V(11, float, 32, 16, true, 1024, 32, 4, 16, 16);  // tuning: radix-4 first sub-pass (eight butterflies per thread)
     // ablation probes of the default 1024-row tile (wrong results by design; MI355FFT_VARIANT=5..8, tuning only)

@@ -46,6 +46,27 @@ template <class T> struct K2Params {
     T sgn_x;           // -1 for the inverse plan (conj on the way in and out), +1 otherwise: every pass of the sequence sees it
 };
 
+// Fused two-pass kernel (kernels.h k2f_decode, launch.h k2f_kernel): ONE launch runs both column-tile passes of every
+// transform of the batch; the intermediate lives in a ring of `ns` transform-sized slots that stays in the Infinity Cache.
+// Work item w (= workgroup index, or a ticket): step s = w / (t0 + t1) holds the t0 first-pass tiles of transform s and the
+// t1 second-pass tiles of transform s - lag.  Dependencies point to earlier steps only:
+//   second-pass tile of transform g : all t0 first-pass tiles of g have been written    (written[g % ns] >= (g / ns + 1) t0)
+//   first-pass tile of transform g  : all t1 second-pass tiles of g - ns have been read  (read[g % ns]    >= (g / ns) t1)
+// ctrl (device, zeroed before every launch): [0] ticket counter, [1] error word (a bounded wait gave up), then per slot two
+// counters on their own 128-byte lines: written at ctrl[32 + 64 slot], read at ctrl[64 + 64 slot].
+template <class T> struct K2FusedParams {
+    K2Params<T> pass[2];   // pass[0].in / pass[1].out: the caller's rows; pass[0].out == pass[1].in: the ring base
+    unsigned* ctrl;
+    int tiles[2];          // t0, t1: tiles per transform of the two passes
+    int lag, ns;
+    long long batch;
+    int mode;              // bit 0: dependency flags + fences (0 = timing probe only, results undefined); bit 1: work items by ticket
+    int spin_limit;        // polls before a wait gives up and sets the error word
+};
+constexpr int k2f_ctrl_words(int ns) { return 32 + 64 * ns + 64; }
+// workgroups of a fused launch: batch + lag steps of t0 + t1 items (the items of a step that have no transform do nothing)
+constexpr long long k2f_grid(long long batch, int t0, int t1, int lag) { return (batch + lag) * (long long)(t0 + t1); }
+
 // Bluestein (chirp-z) in one workgroup, src/algorithm/bluesteins_algorithm.rs:100-136:
 //   a[i] = x[i] * chirp[i] (zero padded to M);  A = FFT_M(a);  A[j] = conj(A[j] * bf[j]);
 //   A = FFT_M(A);  X[i] = conj(A[i]) * chirp[i]

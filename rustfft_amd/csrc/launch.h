@@ -81,6 +81,17 @@ __global__ __launch_bounds__((k2_threads<S, F, ABL>()), (k2_threads<S, F, ABL>()
         static_assert(F % 2 == 0 && !(ABL & 64), "pairs of adjacent columns");
         DevExecPair<T, regs_needed<S, SPLIT>()> ex;
         k2_body<T, S, F, FIRST, SPLIT, ABL>(ex, p, (long long)blockIdx.x, smem);
+    } else if constexpr ((ABL & 8192) != 0) {
+        // tuning: PERSISTENT workgroups (grid = what the chip holds; each walks the tile list with that stride).  The stores of
+        // tile i and the loads of tile i + 1 are in flight together: the barrier between two tiles is a bare s_barrier (it
+        // orders the LDS reuse; the last LDS reads of a tile are complete before its last sub-pass computes), NOT a
+        // __syncthreads(), whose s_waitcnt vmcnt(0) would drain the stores first.
+        DevExec<T, regs_needed<S, SPLIT>()> ex;
+        const long long total = p.batch * p.tiles_per_fft;
+        for (long long b = (long long)blockIdx.x; b < total; b += (long long)gridDim.x) {
+            k2_body<T, S, F, FIRST, SPLIT, ABL>(ex, p, b, smem);
+            __builtin_amdgcn_s_barrier();
+        }
     } else {
         DevExec<T, regs_needed<S, SPLIT>()> ex;
         k2_body<T, S, F, FIRST, SPLIT, ABL>(ex, p, (long long)blockIdx.x, smem);
@@ -150,12 +161,121 @@ template <class T, class S, int F, bool FIRST, bool SPLIT, int ABL = 0> KernelEn
     e.name = name;
     e.launch = [](const void* params, long long grid, void* stream) {
         void* args[] = {const_cast<void*>(params)};
+        if ((ABL & 8192) != 0) {  // persistent: as many workgroups as the chip holds at 128 VGPRs
+            const long long resident = 256LL * (k2_threads<S, F, ABL>() >= 1024 ? 1 : 1024 / k2_threads<S, F, ABL>());
+            if (grid > resident) grid = resident;
+        }
         (void)hipLaunchKernel((const void*)k2_kernel<T, S, F, FIRST, SPLIT, ABL>, dim3((unsigned)grid), dim3(k2_threads<S, F, ABL>()), args,
                               k2_lds_bytes<T, S, F, SPLIT, ABL>(), (hipStream_t)stream);
     };
     e.prepare = []() -> int {
         return (int)hipFuncSetAttribute((const void*)k2_kernel<T, S, F, FIRST, SPLIT, ABL>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)k2_lds_bytes<T, S, F, SPLIT, ABL>());
+    };
+    return e;
+}
+// ---- fused two-pass kernel (K2FusedParams, kernels.h k2f_decode) --------------------------------------------------------------
+// Cross-workgroup protocol (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"): a producer
+// tile's waves drain their stores (s_waitcnt vmcnt(0)), the workgroup barrier collects them, lane 0 issues the agent-scope
+// release (buffer_wbl2 sc1: the XCD's L2 writes its dirty lines back), waits for it (the explicit s_waitcnt: the compiler may
+// drop its own) and bumps the slot's counter with a relaxed agent-scope atomic; a consumer's lane 0 polls the counter with
+// relaxed agent-scope loads (L1-bypassing) and s_sleep, then issues ONE agent-scope acquire (invalidates this CU's L1) before
+// the barrier that releases its waves to plain loads.  Waits are bounded: a wait that gives up sets the error word
+// (ctrl[1]) and the tile proceeds -- the launch always terminates; the host checks the word.
+// Deadlock freedom: a work item only waits for items of EARLIER steps, i.e. lower indices.  With tickets (mode bit 1) every
+// lower index has been claimed by a workgroup that is already running when an item starts to wait.  Without tickets the same
+// holds per XCD because a dispatcher walks its share of the grid in order (identical resource needs, nothing to reorder), and
+// then for the chip: the XCD with the lowest dispatch frontier cannot hold a waiter whose dependency lies beyond a frontier.
+template <class T> __device__ __forceinline__ void k2f_wait(unsigned* ctr, unsigned target, const K2FusedParams<T>& fp) {
+    int spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > fp.spin_limit) {
+            atomicOr(fp.ctrl + 1, 1u);
+            break;
+        }
+    }
+}
+// RINGV: how the ring is accessed -- bit 0: the first pass stores it with agent-scope (write-through) stores, so no release fence;
+// bit 1: the second pass loads it with agent-scope (L1-bypassing) loads, so no acquire fence (cx.h st_agent / ld_agent)
+template <class T, class S0, int F0, bool SPLIT0, int ABL0, class S1, int F1, bool SPLIT1, int ABL1, int RINGV>
+__global__ __launch_bounds__((k2_threads<S0, F0, ABL0>()), (k2_threads<S0, F0, ABL0>() >= 512 ? 4 : 2)) void k2f_kernel(K2FusedParams<T> fp) {
+    static_assert(k2_threads<S0, F0, ABL0>() == k2_threads<S1, F1, ABL1>(), "one block size for both passes");
+    static_assert(!(ABL0 & 4096) && !(ABL1 & 4096), "plain executors");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ unsigned s_ticket;
+    long long w = (long long)blockIdx.x;
+    if (fp.mode & 2) {
+        if (threadIdx.x == 0) s_ticket = atomicAdd(fp.ctrl, 1u);
+        __syncthreads();
+        w = (long long)__builtin_amdgcn_readfirstlane((int)s_ticket);  // workgroup-uniform: everything derived from it stays in SGPRs
+    }
+    const K2FItem it = k2f_decode(fp, w);
+    if (it.pass < 0) return;
+    unsigned* written = fp.ctrl + 32 + 64 * it.slot;
+    unsigned* rd = fp.ctrl + 64 + 64 * it.slot;
+    const long long n = fp.pass[0].n;
+    cx<T>* ring = fp.pass[0].out + (long long)it.slot * n;
+    const bool sync = (fp.mode & 1) != 0;
+    const bool release = sync && !(RINGV & 1) && !(fp.mode & 4), acquire = sync && !(RINGV & 2) && !(fp.mode & 8);  // mode bits 2, 3: probes
+    if (it.pass == 0) {
+        if (sync && it.use > 0) {
+            if (threadIdx.x == 0) k2f_wait(rd, it.use * (unsigned)fp.tiles[1], fp);
+            __syncthreads();
+        }
+        DevExec<T, regs_needed<S0, SPLIT0>()> ex;
+        k2_tile<T, S0, F0, true, SPLIT0, ABL0, (RINGV & 1)>(ex, fp.pass[0], fp.pass[0].in + it.g * n, ring, it.tile, smem);
+        if (sync) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                if (release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(written, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    } else {
+        if (sync) {
+            if (threadIdx.x == 0) {
+                k2f_wait(written, (it.use + 1u) * (unsigned)fp.tiles[0], fp);
+                if (acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+        }
+        DevExec<T, regs_needed<S1, SPLIT1>()> ex;
+        k2_tile<T, S1, F1, false, SPLIT1, ABL1, (RINGV & 2)>(ex, fp.pass[1], (const cx<T>*)ring, fp.pass[1].out + it.g * n, it.tile, smem);
+        if (sync) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(rd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+template <class T, class S0, int F0, bool SPLIT0, int ABL0, class S1, int F1, bool SPLIT1, int ABL1> constexpr size_t k2f_lds_bytes() {
+    return k2_lds_bytes<T, S0, F0, SPLIT0, ABL0>() > k2_lds_bytes<T, S1, F1, SPLIT1, ABL1>() ? k2_lds_bytes<T, S0, F0, SPLIT0, ABL0>() : k2_lds_bytes<T, S1, F1, SPLIT1, ABL1>();
+}
+template <class T, class S0, int F0, bool SPLIT0, int ABL0, class S1, int F1, bool SPLIT1, int ABL1, int RINGV = 1, int VARIANT = 0>
+KernelEntry make_k2f(int prec, const char* name, const char* part0, const char* part1) {
+    KernelEntry e{};
+    e.kind = KIND_K2_FUSED;
+    e.prec = prec;
+    e.n = S0::N * S1::N;
+    e.f = F0;
+    e.f2 = F1;
+    e.threads = k2_threads<S0, F0, ABL0>();
+    e.lds_bytes = k2f_lds_bytes<T, S0, F0, SPLIT0, ABL0, S1, F1, SPLIT1, ABL1>();
+    e.name = name;
+    e.part[0] = part0;
+    e.part[1] = part1;
+    e.variant = VARIANT;
+    e.launch = [](const void* params, long long grid, void* stream) {
+        void* args[] = {const_cast<void*>(params)};
+        (void)hipLaunchKernel((const void*)k2f_kernel<T, S0, F0, SPLIT0, ABL0, S1, F1, SPLIT1, ABL1, RINGV>, dim3((unsigned)grid), dim3(k2_threads<S0, F0, ABL0>()), args,
+                              k2f_lds_bytes<T, S0, F0, SPLIT0, ABL0, S1, F1, SPLIT1, ABL1>(), (hipStream_t)stream);
+    };
+    e.prepare = []() -> int {
+        return (int)hipFuncSetAttribute((const void*)k2f_kernel<T, S0, F0, SPLIT0, ABL0, S1, F1, SPLIT1, ABL1, RINGV>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)k2f_lds_bytes<T, S0, F0, SPLIT0, ABL0, S1, F1, SPLIT1, ABL1>());
     };
     return e;
 }
@@ -462,6 +582,51 @@ template <class T, class S, int F, bool FIRST, bool SPLIT, int ABL = 0> KernelEn
     e.prepare = []() -> int { return 0; };
     return e;
 }
+// Fused two-pass kernel on the host: the work items run one after another in index order; every item CHECKS the dependency
+// counters the device kernel would wait on (an unsatisfied one means the item order is wrong: error word bit 1) and updates them.
+template <class T, class S0, int F0, bool SPLIT0, int ABL0, class S1, int F1, bool SPLIT1, int ABL1> constexpr size_t k2f_lds_bytes() {
+    return k2_lds_bytes<T, S0, F0, SPLIT0, ABL0>() > k2_lds_bytes<T, S1, F1, SPLIT1, ABL1>() ? k2_lds_bytes<T, S0, F0, SPLIT0, ABL0>() : k2_lds_bytes<T, S1, F1, SPLIT1, ABL1>();
+}
+template <class T, class S0, int F0, bool SPLIT0, int ABL0, class S1, int F1, bool SPLIT1, int ABL1, int RINGV = 1, int VARIANT = 0>
+KernelEntry make_k2f(int prec, const char* name, const char* part0, const char* part1) {
+    KernelEntry e{};
+    e.kind = KIND_K2_FUSED;
+    e.variant = VARIANT;
+    e.prec = prec;
+    e.n = S0::N * S1::N;
+    e.f = F0;
+    e.f2 = F1;
+    e.threads = F0 * S0::TPF;
+    e.lds_bytes = k2f_lds_bytes<T, S0, F0, SPLIT0, ABL0, S1, F1, SPLIT1, ABL1>();
+    e.name = name;
+    e.part[0] = part0;
+    e.part[1] = part1;
+    e.launch = [](const void* params, long long grid, void*) {
+        const K2FusedParams<T>& fp = *(const K2FusedParams<T>*)params;
+        std::vector<char> lds(k2f_lds_bytes<T, S0, F0, SPLIT0, ABL0, S1, F1, SPLIT1, ABL1>() + 64, (char)0x5a);
+        const long long n = fp.pass[0].n;
+        for (long long w = 0; w < grid; ++w) {
+            const K2FItem it = k2f_decode(fp, w);
+            if (it.pass < 0) continue;
+            unsigned* written = fp.ctrl + 32 + 64 * it.slot;
+            unsigned* rd = fp.ctrl + 64 + 64 * it.slot;
+            cx<T>* ring = fp.pass[0].out + (long long)it.slot * n;
+            if (it.pass == 0) {
+                if (it.use > 0 && *rd < it.use * (unsigned)fp.tiles[1]) fp.ctrl[1] |= 2u;
+                HostExec<T, regs_needed<S0, SPLIT0>()> ex(F0 * S0::TPF);
+                k2_tile<T, S0, F0, true, SPLIT0, ABL0>(ex, fp.pass[0], fp.pass[0].in + it.g * n, ring, it.tile, lds.data());
+                *written += 1;
+            } else {
+                if (*written < (it.use + 1u) * (unsigned)fp.tiles[0]) fp.ctrl[1] |= 2u;
+                HostExec<T, regs_needed<S1, SPLIT1>()> ex(F1 * S1::TPF);
+                k2_tile<T, S1, F1, false, SPLIT1, ABL1>(ex, fp.pass[1], (const cx<T>*)ring, fp.pass[1].out + it.g * n, it.tile, lds.data());
+                *rd += 1;
+            }
+        }
+    };
+    e.prepare = []() -> int { return 0; };
+    return e;
+}
 template <class T> KernelEntry make_pointwise(int prec) {
     KernelEntry e{};
     e.kind = KIND_POINTWISE;
@@ -653,6 +818,22 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
     reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, true, SPLIT>(PREC, "k2first<" #__VA_ARGS__ ">xF" #F)); \
     reg.push_back(make_k2<T, Sched<__VA_ARGS__>, F, false, SPLIT>(PREC, "k2later<" #__VA_ARGS__ ">xF" #F))
 
+// both passes of a two-pass plan in one launch; NAME0 / NAME1 are the registry names of the one-pass kernels it fuses
+// (the ring is stored with agent-scope write-through stores and read with plain loads behind one acquire per tile: RINGV = 1,
+// the measured choice -- profiles/r4/ab_proto_2p20.jsonl: a release fence per tile costs 8 ms of 11, write-through stores 0.4)
+// AUTO = 1: the planner uses the fused launch for this pair by default (a per-size measured choice, profiles/r4/ab_fused_*.jsonl);
+// 0: compiled, used on request only (mi355fft_plan_set_fused)
+#define MI_K2F(AUTO, T, PREC, NAME0, F0, SP0, ABL0, SCHED0, NAME1, F1, SP1, ABL1, SCHED1)                                                          \
+    reg.push_back(make_k2f<T, SCHED0, F0, SP0, ABL0, SCHED1, F1, SP1, ABL1, 1, 0>(PREC, "k2fused[" NAME0 " | " NAME1 "]", NAME0, NAME1)); \
+    reg.back().aux = AUTO
+// tuning: other ring-access forms (RINGV 0: plain accesses + release / acquire fences, 2: agent-scope loads, 3: both agent-scope),
+// registered as variant 10 + RINGV (MI355FFT_FUSE_RING)
+#if defined(MI355_TUNING)
+#define MI_K2FR(RINGV, T, PREC, NAME0, F0, SP0, ABL0, SCHED0, NAME1, F1, SP1, ABL1, SCHED1) \
+    reg.push_back(make_k2f<T, SCHED0, F0, SP0, ABL0, SCHED1, F1, SP1, ABL1, RINGV, 10 + RINGV>(PREC, "k2fused[" NAME0 " | " NAME1 "]r" #RINGV, NAME0, NAME1))
+#else
+#define MI_K2FR(RINGV, T, PREC, NAME0, F0, SP0, ABL0, SCHED0, NAME1, F1, SP1, ABL1, SCHED1) (void)0
+#endif
 // production instantiations with options (ABL: 64 pair-fused, 128 / 1024 / 2048 sub-pass twiddle tables staged in LDS: all /
 // sub-pass 1 / the last sub-pass); SUF is appended to the kernel name ("t", "t1", "tl")
 #define MI_K1X(T, PREC, F, SPLIT, ABL, SUF, ...) reg.push_back(make_k1<T, Sched<__VA_ARGS__>, F, SPLIT, ABL>(PREC, "k1<" #__VA_ARGS__ ">xF" #F SUF))

@@ -32,6 +32,7 @@ void ensure_registry() {
         register_k1_f64(r);
         register_k2_f32(r);
         register_k2_f64(r);
+        register_k2f_f32(r);
         register_np2_f32(r);
 #if defined(MI355_MINIMAL)
         register_bs57_f32(r);
@@ -190,7 +191,15 @@ Plan::~Plan() {
     DeviceGuard dev(device);
     backend::sync_device();
     for (void* p : device_allocs) backend::dfree(p);
-    for (auto& kv : slots) backend::dfree(kv.second->ws.ptr);
+    for (auto& kv : slots) {
+        backend::dfree(kv.second->ws.ptr);
+        PipeState& pp = kv.second->pipe;
+        backend::dfree(pp.ring.ptr);
+        backend::dfree(pp.ctrl);
+        for (void* s : pp.side) backend::stream_destroy(s);
+        for (void* e : pp.ev) backend::event_destroy(e);
+        if (pp.ev_fork) backend::event_destroy(pp.ev_fork);
+    }
     for (auto* pool : {&host_pool, &host_busy})  // host-slice staging contexts
         for (auto& c : *pool) {
             backend::dfree(c->in.ptr);
@@ -1102,6 +1111,16 @@ int build_plan(Plan& plan) {
     ensure_registry();
     plan.device = backend::current_device();
     plan.dbg = env_int("MI355FFT_DBG");  // measurement knobs (tuning builds only; 0 in the shipped library)
+    if (env_int("MI355FFT_PIPE")) plan.pipe_mode = env_int("MI355FFT_PIPE");
+    if (env_int("MI355FFT_PIPE_MIB")) plan.pipe_slot_bytes = (size_t)env_int("MI355FFT_PIPE_MIB") << 20;
+    if (env_int("MI355FFT_PIPE_SLOTS")) plan.pipe_slots = env_int("MI355FFT_PIPE_SLOTS");
+    if (env_int("MI355FFT_FUSE")) {  // tuning: 4 = fused launch without the dependency protocol (timing probe), 5 = with it, 7 = + tickets, 8 = off
+        plan.fuse_on = env_int("MI355FFT_FUSE") != 8;
+        plan.fuse_mode = env_int("MI355FFT_FUSE") & 3;
+        plan.fuse_mode |= env_int("MI355FFT_FUSE_PROBE") & 12;  // 4: no release fence, 8: no acquire fence (wrong by design)
+    }
+    plan.fuse_lag = env_int("MI355FFT_FUSE_LAG");
+    plan.fuse_slots = env_int("MI355FFT_FUSE_SLOTS");
     struct TwiddleScope {  // the host planner's compute_twiddle, for this thread, for the duration of the build
         TwiddleScope(mi355fft_twiddle_fn f, void* c) {
             t_twiddle_fn = f;
@@ -1112,7 +1131,19 @@ int build_plan(Plan& plan) {
             t_twiddle_ctx = nullptr;
         }
     } scope(plan.tw_fn, plan.tw_ctx);
-    return plan.prec == 32 ? build_plan_t<float>(plan) : build_plan_t<double>(plan);
+    const int rc = plan.prec == 32 ? build_plan_t<float>(plan) : build_plan_t<double>(plan);
+    if (rc) return rc;
+    // a fused two-pass kernel for exactly this pair of column-tile passes, if one is compiled
+    if (plan.kind == PLAN_MACRO && plan.passes.size() == 2 && plan.passes[0].k->kind == KIND_K2_FIRST && plan.passes[1].k->kind == KIND_K2_LATER)
+        for (auto& e : registry())
+            if (e.kind == KIND_K2_FUSED && e.prec == plan.prec && !strcmp(e.part[0], plan.passes[0].k->name) && !strcmp(e.part[1], plan.passes[1].k->name) &&
+                (e.variant == 0 || (env_int("MI355FFT_FUSE_RING") && e.variant == 10 + env_int("MI355FFT_FUSE_RING") - 100))) {
+                if (e.prepare()) return MI355FFT_ERR_HIP;
+                plan.fused = &e;
+                if (e.aux == 1 && env_int("MI355FFT_FUSE") == 0) plan.fuse_on = true;  // the measured default for this length
+                if (e.variant != 0) break;  // tuning: the requested ring-access variant wins over the default
+            }
+    return MI355FFT_OK;
 }
 
 std::string Plan::describe() const {
@@ -1128,8 +1159,9 @@ std::string Plan::describe() const {
         s << ")";
         return s.str();
     }
+    if (fuse_on && fused) s << "fused{";
     for (size_t i = 0; i < passes.size(); ++i) {
-        s << (i ? " -> " : "") << passes[i].k->name;
+        s << (i ? (fuse_on && fused ? " | " : " -> ") : "") << passes[i].k->name;
         if (passes[i].k->kind == KIND_DYN_K1 || passes[i].k->kind == KIND_DYN_RADER) {
             const DynSched& d = passes[i].dyn;
             s << "<" << d.n << ", " << d.tpf;
@@ -1137,6 +1169,7 @@ std::string Plan::describe() const {
             s << ">xF" << d.f;
         }
     }
+    if (fuse_on && fused) s << "}";
     return s.str();
 }
 
@@ -1171,7 +1204,7 @@ size_t Plan::workspace_bytes() {
     size_t total = 0;
     for (StreamSlot* s : all) {  // ws.bytes changes under the slot's launch lock (workspace_in)
         std::lock_guard<std::mutex> g(s->launch_mutex);
-        total += s->ws.bytes;
+        total += s->ws.bytes + s->pipe.ring.bytes;
     }
     return total + (inner ? inner->workspace_bytes() : 0);
 }
@@ -1188,11 +1221,13 @@ size_t Plan::trim_workspaces() {
     }
     for (StreamSlot* s : all) {
         std::lock_guard<std::mutex> g(s->launch_mutex);
-        if (!s->ws.ptr) continue;
+        if (!s->ws.ptr && !s->pipe.ring.ptr) continue;
         backend::sync_device();
-        freed += s->ws.bytes;
+        freed += s->ws.bytes + s->pipe.ring.bytes;
         backend::dfree(s->ws.ptr);
+        backend::dfree(s->pipe.ring.ptr);
         s->ws = Workspace{};
+        s->pipe.ring = Workspace{};
     }
     return freed;
 }
@@ -1201,6 +1236,53 @@ size_t Plan::trim_workspaces() {
 // A grid above the HIP limit cannot be reached with buffers that fit 288 GB (the smallest workgroup moves 4 KiB), but a
 // truncated launch would transform a subset of the rows silently: checked before every launch.
 static const long long kMaxGrid = 0x7fffffffLL;
+// Parameter block of column-tile pass `pi` (power-of-two tiles: general = false, tile width f).
+template <class T>
+static int fill_k2_params(const Plan& plan, size_t pi, const void* in, void* out, size_t batch, bool general, int f, const void* xin, void* xout, K2Params<T>& p) {
+    const PassDesc& pd = plan.passes[pi];
+    const bool inverse = plan.direction == MI355FFT_INVERSE;
+    p.in = (const cx<T>*)in;
+    p.out = (cx<T>*)out;
+    p.tw = (const cx<T>*)pd.d_tw;
+    p.tlo = (const cx<T>*)pd.d_tlo;
+    p.thi = (const cx<T>*)pd.d_thi;
+    p.hshift = pd.hshift;
+    p.lmask = pd.lmask;
+    p.n = pd.row_n ? pd.row_n : (long long)plan.len;
+    p.m = pd.m;
+    p.s = pd.s;
+    p.batch = (long long)batch;
+    p.tab = (const cx<T>*)pd.d_aux1;  // fused Bluestein / Rader passes only
+    p.perm = (const int*)pd.d_perm_in;  // fused Rader: g^(j+1) on the gather pass, g^-(j+1) on the scatter pass; prime tiles: both maps
+    p.perm2 = (const int*)pd.d_perm_out;
+    p.xin = (const cx<T>*)xin;
+    p.xout = (cx<T>*)xout;
+    p.sgn_x = inverse ? (T)-1 : (T)1;
+    p.n_io = (long long)plan.len;
+    p.n_valid = (unsigned)plan.len;
+    p.tiles_per_fft = general ? (pd.m + f - 1) / f : pd.m / f;
+    p.sgn_in = (inverse && pi == 0) ? (T)-1 : (T)1;
+    p.sgn_out = (inverse && pi + 1 == plan.passes.size()) ? (T)-1 : (T)1;
+    p.dbg = plan.dbg;
+    if (!general) {
+        while ((1LL << p.tiles_shift) < p.tiles_per_fft) ++p.tiles_shift;
+        while ((1LL << p.s_shift) < pd.s) ++p.s_shift;
+        if ((1LL << p.tiles_shift) != p.tiles_per_fft || (1LL << p.s_shift) != pd.s) return MI355FFT_ERR_UNSUPPORTED;
+    }
+    if (!general && !(plan.dbg & 2)) {
+        // XCD id at address bits 9..11 of the row segment: tile-index bit k is address bit log2(segment bytes) + k
+        int w = 0;
+        while ((1LL << (w + 1)) <= (long long)f * (long long)(2 * sizeof(T))) ++w;
+        int xp = w < 9 ? 9 - w : 0, xq = 3;
+        if (env_int("MI355FFT_XP")) xp = env_int("MI355FFT_XP") - 1;  // tuning builds only
+        while (xq > 0 && p.tiles_per_fft % (8LL << xq) != 0) --xq;
+        if (p.tiles_per_fft % 8 != 0) xq = 0;
+        if (xp > xq) xp = xq;
+        p.xp = xp;
+        p.xq = xq;
+    }
+    return MI355FFT_OK;
+}
 template <class T>
 static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, size_t batch, void* stream, Tracer* tr, const void* xin = nullptr,
                        void* xout = nullptr) {
@@ -1275,47 +1357,8 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         k.launch(&p, grid, stream);
     } else {
         K2Params<T> p{};
-        p.in = (const cx<T>*)in;
-        p.out = (cx<T>*)out;
-        p.tw = (const cx<T>*)pd.d_tw;
-        p.tlo = (const cx<T>*)pd.d_tlo;
-        p.thi = (const cx<T>*)pd.d_thi;
-        p.hshift = pd.hshift;
-        p.lmask = pd.lmask;
-        p.n = pd.row_n ? pd.row_n : (long long)plan.len;
-        p.m = pd.m;
-        p.s = pd.s;
-        p.batch = (long long)batch;
-        p.tab = (const cx<T>*)pd.d_aux1;  // fused Bluestein / Rader passes only
-        p.perm = (const int*)pd.d_perm_in;  // fused Rader: g^(j+1) on the gather pass, g^-(j+1) on the scatter pass; prime tiles: both maps
-        p.perm2 = (const int*)pd.d_perm_out;
-        p.xin = (const cx<T>*)xin;
-        p.xout = (cx<T>*)xout;
-        p.sgn_x = inverse ? (T)-1 : (T)1;
-        p.n_io = (long long)plan.len;
-        p.n_valid = (unsigned)plan.len;
         const bool general = (k.kind == KIND_K2G_FIRST || k.kind == KIND_K2G_LATER || k.kind >= KIND_K2G_FIRST_CHIRP);  // incl. the prime tiles
-        p.tiles_per_fft = general ? (pd.m + k.f - 1) / k.f : pd.m / k.f;
-        p.sgn_in = (inverse && pi == 0) ? (T)-1 : (T)1;
-        p.sgn_out = (inverse && pi + 1 == plan.passes.size()) ? (T)-1 : (T)1;
-        p.dbg = plan.dbg;
-        if (!general) {
-            while ((1LL << p.tiles_shift) < p.tiles_per_fft) ++p.tiles_shift;
-            while ((1LL << p.s_shift) < pd.s) ++p.s_shift;
-            if ((1LL << p.tiles_shift) != p.tiles_per_fft || (1LL << p.s_shift) != pd.s) return MI355FFT_ERR_UNSUPPORTED;
-        }
-        if (!general && !(plan.dbg & 2)) {
-            // XCD id at address bits 9..11 of the row segment: tile-index bit k is address bit log2(segment bytes) + k
-            int w = 0;
-            while ((1LL << (w + 1)) <= (long long)k.f * (long long)(2 * sizeof(T))) ++w;
-            int xp = w < 9 ? 9 - w : 0, xq = 3;
-            if (env_int("MI355FFT_XP")) xp = env_int("MI355FFT_XP") - 1;  // tuning builds only
-            while (xq > 0 && p.tiles_per_fft % (8LL << xq) != 0) --xq;
-            if (p.tiles_per_fft % 8 != 0) xq = 0;
-            if (xp > xq) xp = xq;
-            p.xp = xp;
-            p.xq = xq;
-        }
+        if (int rc = fill_k2_params<T>(plan, pi, in, out, batch, general, k.f, xin, xout, p)) return rc;
         grid = (long long)batch * p.tiles_per_fft;
         if (grid > kMaxGrid) return MI355FFT_ERR_INVALID_ARG;
         if ((k.kind == KIND_K2G_FIRST || k.kind == KIND_K2G_LATER) && !(plan.dbg & 2)) {
@@ -1325,6 +1368,132 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         k.launch(&p, grid, stream);
     }
     if (tr) tr->after((int)pi, stream);
+    return backend::check_launch() ? MI355FFT_ERR_HIP : MI355FFT_OK;
+}
+
+
+// ---- chunk pipeline of the multi-pass plans ------------------------------------------------------------------------------
+// A P-pass plan moves every element 2 P times between the CUs and memory.  With one full-size workspace all of it is HBM traffic:
+// pass p + 1 starts after pass p has written the whole batch (8 GiB at config 2), long after the 256 MiB Infinity Cache has lost
+// it.  Here the batch runs in CHUNKS of a few transforms through a small ring of intermediate buffers (2 slots of <= 64 MiB per
+// intermediate): pass p + 1 of chunk c reads what pass p wrote microseconds earlier, and the next chunk overwrites the slot
+// before its lines need to go anywhere -- the intermediates live in the Infinity Cache, HBM sees one read and one write of the
+// caller's buffer per TRANSFORM instead of per pass (tools/mallbench: a tile copy through a 64 MiB ring moves 4 GiB in 2.4 ms
+// against 3.1 ms through a 4 GiB workspace).  Mode 2 puts every pass but the last on a side stream, ordered by events, so
+// pass p of chunk c + 1 overlaps pass p + 1 of chunk c: HBM reads, ring traffic and HBM writes are in flight together and no
+// launch boundary drains the chip.  The caller's buffers are touched by the first pass (reads chunk c of `in`) and the last
+// (writes chunk c of `out`) only, so all three API modes are the same code and `in` is never clobbered.  The last pass runs
+// on the caller's stream and depends on everything else, so the call stays asynchronous and stream-ordered for the caller
+// (and capturable: the side streams fork from and join the caller's stream through events).
+template <class T> static int execute_pipelined(Plan& plan, const void* in, void* out, size_t batch, void* stream) {
+    const size_t esz = 2 * sizeof(T), n = plan.len, P = plan.passes.size();
+    const size_t slot_target = plan.pipe_slot_bytes ? plan.pipe_slot_bytes : ((size_t)64 << 20);
+    size_t C = std::max<size_t>(1, slot_target / (n * esz));
+    if (C > batch) C = batch;
+    const size_t NS = plan.pipe_slots > 0 ? (size_t)plan.pipe_slots : 2, slot_bytes = C * n * esz;
+    const bool overlap = plan.pipe_mode >= 2;
+    StreamSlot& slot = plan.slot_for(stream);
+    std::lock_guard<std::mutex> launch_lock(slot.launch_mutex);
+    PipeState& pp = slot.pipe;
+    const size_t need = (P - 1) * NS * slot_bytes;
+    if (pp.ring.bytes < need) {
+        if (pp.ring.ptr) {
+            backend::sync(stream);  // earlier calls' last passes (which depend on everything the side streams did)
+            backend::dfree(pp.ring.ptr);
+        }
+        pp.ring.ptr = backend::dmalloc(need);
+        pp.ring.bytes = pp.ring.ptr ? need : 0;
+        if (!pp.ring.ptr) return MI355FFT_ERR_OUT_OF_MEMORY;
+    }
+    if (overlap) {
+        while (pp.side.size() < P - 1) {
+            void* s = backend::stream_create();
+            if (!s) return MI355FFT_ERR_HIP;
+            pp.side.push_back(s);
+        }
+        while (pp.ev.size() < P * NS) {
+            void* e = backend::event_create_notiming();
+            if (!e) return MI355FFT_ERR_HIP;
+            pp.ev.push_back(e);
+        }
+        if (!pp.ev_fork && !(pp.ev_fork = backend::event_create_notiming())) return MI355FFT_ERR_HIP;
+        backend::event_record(pp.ev_fork, stream);  // the side streams start behind whatever the caller has enqueued so far
+        for (size_t p = 0; p + 1 < P; ++p) backend::stream_wait_event(pp.side[p], pp.ev_fork);
+    }
+    char* ring = (char*)pp.ring.ptr;
+    size_t ci = 0;
+    for (size_t c0 = 0; c0 < batch; c0 += C, ++ci) {
+        const size_t rows = std::min(C, batch - c0), sl = ci % NS;
+        for (size_t p = 0; p < P; ++p) {
+            void* sp = (overlap && p + 1 < P) ? pp.side[p] : stream;
+            const char* src = p == 0 ? (const char*)in + c0 * n * esz : ring + ((p - 1) * NS + sl) * slot_bytes;
+            char* dst = p + 1 == P ? (char*)out + c0 * n * esz : ring + (p * NS + sl) * slot_bytes;
+            if (overlap) {
+                if (p > 0) backend::stream_wait_event(sp, pp.ev[(p - 1) * NS + sl]);                 // my input is written
+                if (p + 1 < P && ci >= NS) backend::stream_wait_event(sp, pp.ev[(p + 1) * NS + sl]);  // my output slot has been read
+            }
+            int rc = launch_pass<T>(plan, p, src, dst, rows, sp, nullptr, nullptr, nullptr);
+            if (rc) return rc;
+            if (overlap) backend::event_record(pp.ev[p * NS + sl], sp);
+        }
+    }
+    return MI355FFT_OK;
+}
+
+
+// ---- fused two-pass launch ---------------------------------------------------------------------------------------------------
+// Both passes of a two-pass power-of-two plan in ONE launch (launch.h k2f_kernel): pass 2 of transform g - lag runs beside
+// pass 1 of transform g, the intermediate goes through a ring of `ns` transform-sized slots that stays in the Infinity Cache
+// (HBM sees one read and one write per transform), and there is no launch boundary at which the chip drains.  lag and ns follow
+// from how many transforms are in flight: F = ceil(workgroups the chip holds / tiles per step); lag = F + 1 steps (the first-pass
+// tiles of a transform have retired when its second-pass tiles come up), ns = lag + F + 1 slots (a slot is not rewritten while a
+// resident second-pass tile can still read it -- the counters enforce it; the slack only keeps anybody from waiting).
+template <class T> static int execute_fused(Plan& plan, const void* in, void* out, size_t batch, void* stream) {
+    const KernelEntry& k = *plan.fused;
+    const size_t esz = 2 * sizeof(T), n = plan.len;
+    K2FusedParams<T> fp{};
+    if (int rc = fill_k2_params<T>(plan, 0, in, nullptr, batch, false, k.f, nullptr, nullptr, fp.pass[0])) return rc;
+    if (int rc = fill_k2_params<T>(plan, 1, nullptr, out, batch, false, k.f2, nullptr, nullptr, fp.pass[1])) return rc;
+    const int t0 = (int)fp.pass[0].tiles_per_fft, t1 = (int)fp.pass[1].tiles_per_fft;
+    const int resident = 256 * (k.threads >= 1024 ? 1 : 2);  // workgroups the chip holds (128 VGPRs: 16 waves per CU)
+    const int inflight = (resident + t0 + t1 - 1) / (t0 + t1);
+    int lag = plan.fuse_lag > 0 ? plan.fuse_lag : inflight + 1;
+    int ns = plan.fuse_slots > 0 ? plan.fuse_slots : lag + inflight + 1;
+    if (lag < 1) lag = 1;         // a second-pass tile waits for first-pass tiles of an EARLIER step (lower indices) only
+    if (ns <= lag) ns = lag + 1;  // a first-pass tile of step s waits for second-pass tiles of step s - ns + lag: an earlier step as well
+    if (batch < (size_t)ns) return MI355FFT_ERR_UNSUPPORTED;  // fewer transforms than ring slots: nothing to overlap
+    StreamSlot& slot = plan.slot_for(stream);
+    std::lock_guard<std::mutex> launch_lock(slot.launch_mutex);
+    PipeState& pp = slot.pipe;
+    const size_t need = (size_t)ns * n * esz, cbytes = (size_t)k2f_ctrl_words(ns) * sizeof(unsigned);
+    if (pp.ring.bytes < need || pp.ctrl_bytes < cbytes) {
+        backend::sync(stream);
+        if (pp.ring.bytes < need) {
+            backend::dfree(pp.ring.ptr);
+            pp.ring.ptr = backend::dmalloc(need);
+            pp.ring.bytes = pp.ring.ptr ? need : 0;
+        }
+        if (pp.ctrl_bytes < cbytes) {
+            backend::dfree(pp.ctrl);
+            pp.ctrl = backend::dmalloc(cbytes);
+            pp.ctrl_bytes = pp.ctrl ? cbytes : 0;
+        }
+        if (!pp.ring.ptr || !pp.ctrl) return MI355FFT_ERR_OUT_OF_MEMORY;
+    }
+    fp.pass[0].out = (cx<T>*)pp.ring.ptr;
+    fp.pass[1].in = (const cx<T>*)pp.ring.ptr;
+    fp.ctrl = (unsigned*)pp.ctrl;
+    fp.tiles[0] = t0;
+    fp.tiles[1] = t1;
+    fp.lag = lag;
+    fp.ns = ns;
+    fp.batch = (long long)batch;
+    fp.mode = plan.fuse_mode;
+    fp.spin_limit = 1 << 21;  // x s_sleep(8) ~ 0.5 us each: about a second
+    const long long grid = k2f_grid((long long)batch, t0, t1, lag);
+    if (grid > kMaxGrid) return MI355FFT_ERR_INVALID_ARG;
+    if (backend::memset_async(pp.ctrl, 0, cbytes, stream)) return MI355FFT_ERR_HIP;
+    k.launch(&fp, grid, stream);
     return backend::check_launch() ? MI355FFT_ERR_HIP : MI355FFT_OK;
 }
 
@@ -1419,6 +1588,11 @@ template <class T> static int execute_t(Plan& plan, const void* in, void* out, s
     }
     const size_t P = plan.passes.size();
     if (P == 1) return launch_pass<T>(plan, 0, in, out, batch, stream, tr);
+    if (plan.fuse_on && plan.fused && tr == nullptr && P == 2) {
+        const int rcf = execute_fused<T>(plan, in, out, batch, stream);
+        if (rcf != MI355FFT_ERR_UNSUPPORTED) return rcf;  // a batch too small to pipeline runs as two launches
+    }
+    if (plan.pipe_mode > 0 && tr == nullptr && plan.kind == PLAN_MACRO) return execute_pipelined<T>(plan, in, out, batch, stream);
 
     // Buffer rotation.  Every pass but the last is out-of-place; the last one may run in place.
     //   in-place : buf -> ws -> buf -> ws ... -> buf

@@ -59,9 +59,20 @@ struct Workspace {
 // on different streams get different slots and run concurrently.  Growth synchronises on the stream of the call that
 // asks for it (a live handle by construction); the plan's destructor drains the whole device instead of the cached
 // stream handles, which the caller may have destroyed by then.
+// Chunk pipeline of the multi-pass plans (plan.cpp execute_pipelined): a small ring of intermediate buffers that stays in the
+// Infinity Cache, side streams for every pass but the last, ordering-only events [pass * slots + slot].
+struct PipeState {
+    Workspace ring;
+    std::vector<void*> side;
+    std::vector<void*> ev;
+    void* ev_fork = nullptr;
+    void* ctrl = nullptr;  // fused two-pass kernel: control block (ticket, error word, per-slot counters)
+    size_t ctrl_bytes = 0;
+};
 struct StreamSlot {
     std::mutex launch_mutex;
     Workspace ws;
+    PipeState pipe;
 };
 
 // per-kernel event hooks for mi355fft_profile_inplace_dev
@@ -79,6 +90,16 @@ struct Plan {
     std::vector<void*> device_allocs;
     size_t chunk_batch = 0;
     int dbg = 0;
+    // chunk pipeline (execute_pipelined): 0 = off (one full-size workspace), 1 = chunks through a cache-resident ring on the caller's
+    // stream, 2 = the same with every pass but the last on side streams (passes of neighbouring chunks overlap)
+    int pipe_mode = 0;
+    size_t pipe_slot_bytes = 0;  // bytes of one ring slot (0 = default)
+    int pipe_slots = 0;          // ring slots per intermediate buffer (0 = default)
+    // fused two-pass kernel (launch.h k2f_kernel): the registry entry that fuses this plan's two passes (nullptr: none), whether
+    // execute() uses it, its protocol mode (K2FusedParams::mode) and, for experiments, lag / ring slots (0 = derived)
+    const KernelEntry* fused = nullptr;
+    bool fuse_on = false;
+    int fuse_mode = 3, fuse_lag = 0, fuse_slots = 0;  // mode 3: dependency counters + work items by ticket
     // mi355fft_plan_options (host planner in charge): algorithm family, twiddle source, finished tables
     int algorithm = 0;
     mi355fft_twiddle_fn tw_fn = nullptr;

@@ -17,7 +17,10 @@ enum KernelKind { KIND_K1 = 1, KIND_K2_FIRST = 2, KIND_K2_LATER = 3, KIND_RADER 
                   // scatter on the last store of the second one
                   KIND_K2G_FIRST_GATHER = 16, KIND_K2G_LAST_RMUL = 17, KIND_K2G_LAST_SCATTER = 18,
                   // column-tile passes whose tile height is a PRIME: Rader inside the tile (k2r_body); n = the prime
-                  KIND_K2R_FIRST = 19, KIND_K2R_LATER = 20 };
+                  KIND_K2R_FIRST = 19, KIND_K2R_LATER = 20,
+                  // both column-tile passes of a two-pass power-of-two plan in ONE launch (launch.h k2f_kernel); n = N, part[] = the names of
+                  // the two one-pass kernels it fuses
+                  KIND_K2_FUSED = 21 };
 
 struct KernelEntry {
     int kind;
@@ -34,6 +37,8 @@ struct KernelEntry {
     const char* name;
     void (*launch)(const void* params, long long grid, void* stream);
     int (*prepare)();  // one-time setup (dynamic-LDS attribute); returns 0 on success
+    const char* part[2];  // KIND_K2_FUSED: names of the first-pass and second-pass kernels this entry fuses
+    int f2;               // KIND_K2_FUSED: tile width of the second pass (f = the first pass's)
 };
 
 std::vector<KernelEntry>& registry();
@@ -44,6 +49,7 @@ void register_k1_f32(std::vector<KernelEntry>&);
 void register_k1_f64(std::vector<KernelEntry>&);
 void register_k2_f32(std::vector<KernelEntry>&);
 void register_k2_f64(std::vector<KernelEntry>&);
+void register_k2f_f32(std::vector<KernelEntry>&);  // fused two-pass kernels (kernels_k2f_f32.hip)
 void register_np2_f32(std::vector<KernelEntry>&);  // non-power-of-two: mixed radix, Rader, Bluestein
 void register_np2_f64(std::vector<KernelEntry>&);
 void register_bs57_f32(std::vector<KernelEntry>&);  // Bluestein bodies over 5 * 2^k and 7 * 2^k

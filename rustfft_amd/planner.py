@@ -234,6 +234,19 @@ class Fft:
     def set_chunk_batch(self, chunk_batch):
         self._check(self._lib.mi355fft_plan_set_chunk_batch(self._h, int(chunk_batch)))
 
+    def set_fused(self, mode):
+        """Fused two-pass launch: -1 = the planner's measured choice, 0 = never, 1 = whenever a fused kernel exists."""
+        self._check(self._lib.mi355fft_plan_set_fused(self._h, int(mode)))
+
+    def is_fused(self):
+        return bool(self._lib.mi355fft_plan_is_fused(self._h))
+
+    def fused_status(self):
+        """Error word of the plan's most recent fused two-pass launch on torch's current stream (synchronises it); 0 = fine."""
+        w = ctypes.c_uint(0)
+        self._check(self._lib.mi355fft_plan_fused_status(self._h, self._stream(), ctypes.byref(w)))
+        return int(w.value)
+
     def workspace_bytes(self):
         """HBM the plan currently holds as per-stream workspaces."""
         return int(self._lib.mi355fft_plan_workspace_bytes(self._h))
@@ -269,6 +282,8 @@ class Fft:
     def _stream():
         import torch
 
+        if not torch.cuda.is_available():  # the kernel-body emulator of the CPU tests: no streams
+            return ctypes.c_void_p(0)
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def _validate_dev(self, n_in, n_out=None):
@@ -418,6 +433,166 @@ class FftPlannerHip:
 
     def plan_fft_inverse(self, len):
         return self.plan_fft(len, FftDirection.Inverse)
+
+
+class FftMulti:
+    """One `Arc<dyn Fft<T>>` over several GPUs (mi355fft_multi_plan): the rows of a batched call are sharded across the
+    devices by `shard_rows` (the chunk loop of src/array_utils.rs:151-177 is the shard axis), no collective in the data
+    path.  Host slices (numpy) go through the three trait methods unchanged; device-resident data is a LIST of per-device
+    torch tensors, shard g holding rows `shard_rows(batch, g)` on `devices()[g]`."""
+
+    def __init__(self, lib, handle, dtype):
+        self._lib, self._h, self.dtype = lib, handle, np.dtype(dtype)
+        self._replica = lib.mi355fft_multi_plan_replica(handle, 0)
+        self._len = lib.mi355fft_plan_len(self._replica)
+        self._dir = FftDirection(lib.mi355fft_plan_direction(self._replica))
+
+    def __del__(self):
+        try:
+            self._lib.mi355fft_multi_plan_destroy(self._h)
+        except Exception:
+            pass
+
+    def len(self):
+        return self._len
+
+    def fft_direction(self):
+        return self._dir
+
+    def get_inplace_scratch_len(self):
+        return 0
+
+    def get_outofplace_scratch_len(self):
+        return 0
+
+    def get_immutable_scratch_len(self):
+        return 0
+
+    def shards(self):
+        return self._lib.mi355fft_multi_plan_shards(self._h)
+
+    def devices(self):
+        return [self._lib.mi355fft_multi_plan_device(self._h, g) for g in range(self.shards())]
+
+    def shard_rows(self, batch, shard):
+        first, rows = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        self._check(self._lib.mi355fft_shard_rows(int(batch), self.shards(), int(shard), ctypes.byref(first), ctypes.byref(rows)))
+        return int(first.value), int(rows.value)
+
+    def describe(self):
+        buf = ctypes.create_string_buffer(1024)
+        self._lib.mi355fft_plan_describe(self._replica, buf, 1024)
+        return "%d shards on devices %s: %s" % (self.shards(), self.devices(), buf.value.decode())
+
+    def _check(self, rc):
+        if rc != 0:
+            raise FftPanic(rc, self._lib.mi355fft_last_error().decode() or self._lib.mi355fft_strerror(rc).decode())
+
+    _host = Fft._host
+
+    # ---- the trait methods on host slices ----------------------------------------------------------------
+    def process(self, buffer):
+        self.process_with_scratch(buffer, None)
+
+    def process_with_scratch(self, buffer, scratch=None):
+        if isinstance(buffer, (list, tuple)):
+            return self._dev_call(self._lib.mi355fft_multi_process_inplace_dev, buffer, None)
+        p, n = self._host(buffer, True)
+        self._check(self._lib.mi355fft_multi_process_inplace_host(self._h, p, n, None, 0))
+
+    def process_outofplace_with_scratch(self, input, output, scratch=None):
+        if isinstance(input, (list, tuple)):
+            return self._dev_call(self._lib.mi355fft_multi_process_outofplace_dev, input, output)
+        pi, ni = self._host(input, True)
+        po, no = self._host(output, True)
+        self._check(self._lib.mi355fft_multi_process_outofplace_host(self._h, pi, ni, po, no, None, 0))
+
+    def process_immutable_with_scratch(self, input, output, scratch=None):
+        if isinstance(input, (list, tuple)):
+            return self._dev_call(self._lib.mi355fft_multi_process_immutable_dev, input, output)
+        pi, ni = self._host(input, False)
+        po, no = self._host(output, True)
+        self._check(self._lib.mi355fft_multi_process_immutable_host(self._h, pi, ni, po, no, None, 0))
+
+    # ---- device-resident shards -----------------------------------------------------------------------------
+    def _ptrs(self, tensors):
+        arr = (ctypes.c_void_p * self.shards())()
+        for g, t in enumerate(tensors):
+            arr[g] = t.data_ptr() if t is not None and t.numel() else None
+        return arr
+
+    def _streams(self):
+        import torch
+
+        arr = (ctypes.c_void_p * self.shards())()
+        if torch.cuda.is_available():  # (the kernel-body emulator of the CPU tests has no streams: NULL = default)
+            for g, d in enumerate(self.devices()):
+                arr[g] = torch.cuda.current_stream(d).cuda_stream
+        return arr
+
+    def _dev_call(self, fn, a, b):
+        if len(a) != self.shards() or (b is not None and len(b) != self.shards()):
+            raise ValueError("one tensor per shard")
+        batch = sum(t.numel() for t in a) // self._len if self._len else 0
+        for g, t in enumerate(a):  # the tensors must hold exactly their shard's rows
+            if t.numel() != self.shard_rows(batch, g)[1] * self._len:
+                raise ValueError(f"shard {g}: expected {self.shard_rows(batch, g)[1]} rows of {self._len}")
+        if b is None:
+            self._check(fn(self._h, self._ptrs(a), batch, self._streams()))
+        else:
+            self._check(fn(self._h, self._ptrs(a), self._ptrs(b), batch, self._streams()))
+
+    def synchronize(self):
+        self._check(self._lib.mi355fft_multi_synchronize(self._h, self._streams()))
+
+    def scatter(self, root, shards, root_device=None):
+        """Peer copies of every shard's rows out of `root` (a CUDA tensor with the whole batch) into `shards`."""
+        batch = root.numel() // self._len
+        dev = root.device.index if root_device is None else root_device
+        self._check(self._lib.mi355fft_multi_scatter_dev(self._h, ctypes.c_void_p(root.data_ptr()), dev, self._ptrs(shards), batch, self._streams()))
+
+    def gather(self, shards, root, root_device=None):
+        batch = root.numel() // self._len
+        dev = root.device.index if root_device is None else root_device
+        self._check(self._lib.mi355fft_multi_gather_dev(self._h, self._ptrs(shards), ctypes.c_void_p(root.data_ptr()), dev, batch, self._streams()))
+
+
+class FftPlannerHipMulti:
+    """`FftPlannerHip` over every (or the listed) gfx950 device of the node: `plan_fft*` return `FftMulti` objects whose
+    process*() calls shard the batch rows across the devices behind the unchanged trait surface."""
+
+    def __init__(self, dtype=np.complex64, devices=None, lib=None):
+        self._lib = lib or _native.load()
+        self.dtype = np.dtype(dtype)
+        self._prec = _precision(dtype)
+        if self._lib.mi355fft_device_count() <= 0:
+            raise FftPanic(1, "no gfx950 device")
+        self._devices = None if devices is None else [int(d) for d in devices]
+        self._cache = {}
+
+    def plan_fft(self, len, direction):
+        direction = FftDirection(direction)
+        key = (int(len), direction)
+        if key not in self._cache:
+            h = ctypes.c_void_p()
+            if self._devices is None:
+                devs, nd = None, 0
+            else:
+                devs, nd = (ctypes.c_int * len_(self._devices))(*self._devices), len_(self._devices)
+            rc = self._lib.mi355fft_multi_plan_create(int(len), int(direction), self._prec, None, devs, nd, ctypes.byref(h))
+            if rc != 0:
+                raise FftPanic(rc, self._lib.mi355fft_last_error().decode() or self._lib.mi355fft_strerror(rc).decode())
+            self._cache[key] = FftMulti(self._lib, h, self.dtype)
+        return self._cache[key]
+
+    def plan_fft_forward(self, len):
+        return self.plan_fft(len, FftDirection.Forward)
+
+    def plan_fft_inverse(self, len):
+        return self.plan_fft(len, FftDirection.Inverse)
+
+
+len_ = len  # the trait's `len` argument name shadows the builtin inside plan_fft
 
 
 # `FftPlanner::new()` picks the best available back-end (src/plan.rs:72-94); here the only back-end is HIP.

@@ -1,0 +1,222 @@
+"""CPU checks (kernel-body emulator, tests/emu) of the round-4 host logic: the fused two-pass launch (work-item order,
+dependency counters, ring slot reuse), the chunk pipeline, and the multi-device plan (row sharding, per-shard workers, the
+trait's validation semantics through it).  The emulator runs the fused kernel's work items in index order and CHECKS every
+dependency the device kernel would wait on: an item order that could deadlock or read an unwritten slot sets the error word."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import compare_vectors, numpy_fft, random_signal, rel_l2
+
+EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    subprocess.check_call(["make", "-C", EMU_DIR, "-j", "8", "-s"])
+    from rustfft_amd import _native
+
+    return _native.load(os.path.join(EMU_DIR, "libmi355fft_emu.so"))
+
+
+def _planner(lib, dtype=np.complex64):
+    import rustfft_amd
+
+    return rustfft_amd.FftPlannerHip(dtype, lib=lib)
+
+
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("log2n,lag,slots,batch", [(16, 1, 2, 5), (16, 2, 5, 7), (17, 1, 3, 4), (18, 1, 2, 3), (19, 1, 2, 3), (21, 1, 2, 2)])
+def test_fused_two_pass_launch_matches_two_launches(emu_lib, oracle, log2n, lag, slots, batch):
+    """Every fused kernel against the two-launch plan of the same length, with a ring so small that slots are reused (a first-pass
+    tile has to find its slot read, a second-pass tile its slot written): bit-identical results, error word 0."""
+    n = 1 << log2n
+    ref = _planner(emu_lib).plan_fft_forward(n)
+    ref.set_fused(0)
+    fus = _with_env({"MI355FFT_FUSE_LAG": lag, "MI355FFT_FUSE_SLOTS": slots}, lambda: _planner(emu_lib).plan_fft_forward(n))
+    fus.set_fused(1)
+    assert fus.is_fused() and "fused{" in fus.describe() and not ref.is_fused()
+    x = random_signal(n * batch, np.complex64)
+    a, b = x.copy(), x.copy()
+    ref.process(a)
+    fus.process(b)
+    assert np.array_equal(a, b)
+    assert fus.fused_status() == 0
+    want = x[:n].copy()
+    oracle.plan(np.complex64, n, 0).process(want)
+    assert compare_vectors(want, b[:n])
+    # the other two API modes run the same launch: the input is never clobbered
+    y = np.empty_like(x)
+    fus.process_immutable_with_scratch(x, y)
+    assert np.array_equal(y, a)
+    x2, y2 = x.copy(), np.empty_like(x)
+    fus.process_outofplace_with_scratch(x2, y2)
+    assert np.array_equal(y2, a) and fus.fused_status() == 0
+
+
+def test_fused_default_ring_and_small_batches(emu_lib):
+    """The default lag / ring (from the number of resident workgroups) at config 2's length; a batch smaller than the ring runs
+    as two launches (nothing to overlap), a larger one fused -- same results."""
+    n = 1 << 20
+    fus = _planner(emu_lib).plan_fft_forward(n)
+    assert fus.is_fused()  # the planner's default at 2^20 (measured: profiles/r4)
+    ref = _planner(emu_lib).plan_fft_forward(n)
+    ref.set_fused(0)
+    for batch in (1, 12):
+        x = random_signal(n * batch, np.complex64)
+        a, b = x.copy(), x.copy()
+        ref.process(a)
+        fus.process(b)
+        assert np.array_equal(a, b) and fus.fused_status() == 0
+    inv = _planner(emu_lib).plan_fft_inverse(n)
+    x = random_signal(n * 11, np.complex64)
+    y = x.copy()
+    fus.process(y)
+    inv.process(y)
+    assert rel_l2(y / n, x) < 2e-6 and inv.fused_status() == 0
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_chunk_pipeline_matches_full_workspace(emu_lib, mode):
+    """Chunks through a ring of intermediate buffers (tuning builds: MI355FFT_PIPE), two- and three-pass plans, all API modes."""
+    for n, batch in ((1 << 16, 9), (1 << 23, 3)):
+        ref = _planner(emu_lib).plan_fft_forward(n)
+        ref.set_fused(0)
+        pip = _with_env({"MI355FFT_PIPE": mode, "MI355FFT_PIPE_MIB": 1 if n < (1 << 20) else 128, "MI355FFT_FUSE": 8}, lambda: _planner(emu_lib).plan_fft_forward(n))
+        x = random_signal(n * batch, np.complex64)
+        a, b = x.copy(), x.copy()
+        ref.process(a)
+        pip.process(b)
+        assert np.array_equal(a, b)
+        y = np.empty_like(x)
+        pip.process_immutable_with_scratch(x, y)
+        assert np.array_equal(y, a)
+
+
+# ---- multi-device plan -------------------------------------------------------------------------------------------------------
+def _multi(lib, n, direction, devices, dtype=np.complex64):
+    import rustfft_amd
+
+    return rustfft_amd.FftPlannerHipMulti(dtype, devices=devices, lib=lib).plan_fft(n, direction)
+
+
+def test_shard_rows_is_the_law_of_sharding_py(emu_lib):
+    from rustfft_amd.sharding import shard_rows
+
+    first, rows = ctypes.c_size_t(), ctypes.c_size_t()
+    for batch in (0, 1, 2, 7, 8, 9, 1000, 1024, 8192):
+        for world in (1, 2, 3, 8):
+            covered = 0
+            for r in range(world):
+                assert emu_lib.mi355fft_shard_rows(batch, world, r, ctypes.byref(first), ctypes.byref(rows)) == 0
+                lo, hi = shard_rows(batch, world, r)
+                assert (first.value, first.value + rows.value) == (lo, hi)
+                covered += rows.value
+            assert covered == batch
+    assert emu_lib.mi355fft_shard_rows(4, 2, 2, ctypes.byref(first), ctypes.byref(rows)) != 0
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_multi_device_host_slices(emu_lib, oracle, dtype, monkeypatch):
+    """The three trait methods through a plan over two (fake) devices and over the SAME device twice: results equal the
+    one-device plan's, whatever the batch (ragged shards, an empty shard, a single row)."""
+    from rustfft_amd import FftPanic
+
+    monkeypatch.setenv("MI355_EMU_DEVICES", "3")
+    for n in (1200 if dtype == np.complex128 else 1009, 1 << 16):
+        one = _planner(emu_lib, dtype).plan_fft_forward(n)
+        for devices in ([0, 1], [2, 2], [0, 1, 2]):
+            multi = _multi(emu_lib, n, 0, devices, dtype)
+            assert multi.shards() == len(devices) and multi.devices() == devices and multi.len() == n
+            for batch in (1, 2, 5):
+                x = random_signal(n * batch, dtype)
+                want = x.copy()
+                one.process(want)
+                a = x.copy()
+                multi.process(a)
+                assert np.array_equal(a, want)
+                y = np.empty_like(x)
+                multi.process_immutable_with_scratch(x, y)
+                assert np.array_equal(y, want)
+                x2, y2 = x.copy(), np.empty_like(x)
+                multi.process_outofplace_with_scratch(x2, y2)
+                assert np.array_equal(y2, want)
+            ref = x[:n].copy()
+            oracle.plan(dtype, n, 0).process(ref)
+            assert compare_vectors(ref, want[:n])
+        # validation semantics of src/common.rs:13-104 through the multi-device entry points
+        multi = _multi(emu_lib, n, 0, [0, 1], dtype)
+        x = random_signal(n * 3 + 5, dtype)
+        want = x.copy()
+        with pytest.raises(FftPanic, match="multiple of FFT length"):
+            one.process(want)
+        got = x.copy()
+        with pytest.raises(FftPanic, match="multiple of FFT length"):
+            multi.process(got)
+        assert np.array_equal(got, want)  # the complete chunks WERE transformed before the panic (array_utils.rs:164-176)
+        with pytest.raises(FftPanic, match="too small"):
+            multi.process(random_signal(n - 1, dtype))
+        with pytest.raises(FftPanic, match="same length"):
+            multi.process_outofplace_with_scratch(random_signal(n, dtype), np.empty(2 * n, dtype))
+        multi.process(np.empty(0, dtype))  # an empty buffer is accepted
+    with pytest.raises(FftPanic):
+        _multi(emu_lib, 64, 0, [0, 7], dtype)  # no such device
+
+
+class _Dev:
+    """numpy array standing in for a device tensor (the emulator's device memory is host memory)."""
+
+    def __init__(self, a):
+        self.a = a
+
+    def data_ptr(self):
+        return self.a.ctypes.data
+
+    def numel(self):
+        return self.a.size
+
+
+def test_multi_device_resident_shards_and_edges(emu_lib, monkeypatch):
+    monkeypatch.setenv("MI355_EMU_DEVICES", "2")
+    n, batch = 1 << 16, 5
+    multi = _multi(emu_lib, n, 0, [0, 1])
+    one = _planner(emu_lib).plan_fft_forward(n)
+    x = random_signal(n * batch, np.complex64)
+    want = x.copy()
+    one.process(want)
+    shards = []
+    for g in range(2):
+        lo, rows = multi.shard_rows(batch, g)
+        shards.append(np.zeros(rows * n, np.complex64))
+    root = _Dev(x.copy())
+    root.device = None
+    multi.scatter(root, [_Dev(s) for s in shards], root_device=0)
+    assert np.array_equal(np.concatenate(shards), x)
+    multi.process([_Dev(s) for s in shards])
+    multi.synchronize()
+    assert np.array_equal(np.concatenate(shards), want)
+    out = _Dev(np.zeros_like(x))
+    multi.gather([_Dev(s) for s in shards], out, root_device=0)
+    assert np.array_equal(out.a, want)
+    # out of place / immutable on device-resident shards
+    ins = [x[: 3 * n].copy(), x[3 * n:].copy()]
+    outs = [np.zeros(3 * n, np.complex64), np.zeros(2 * n, np.complex64)]
+    multi.process_immutable_with_scratch([_Dev(a) for a in ins], [_Dev(a) for a in outs])
+    assert np.array_equal(np.concatenate(outs), want) and np.array_equal(np.concatenate(ins), x)
+    with pytest.raises(ValueError):
+        multi.process([_Dev(shards[1]), _Dev(shards[0])])  # the shards must hold their own rows
