@@ -264,6 +264,12 @@ int mi355fft_plan_is_fused(const mi355fft_plan* plan);
  * error word instead of hanging the GPU.  This call synchronises `stream` and returns the word of the plan's most recent fused
  * launch on that stream through *error_word (0 = every dependency was met in time; also 0 when the plan never ran fused). */
 int mi355fft_plan_fused_status(const mi355fft_plan* plan, void* stream, unsigned* error_word);
+/* Workspace placement (off by default).  Identical multi-pass plans run up to 3.6 % apart depending on which device allocation
+ * holds their in-place workspace (profiles/r3/ab_ws_placement.jsonl).  With on = 1, the FIRST in-place call of a (plan, stream)
+ * whose workspace is 256 MiB or more tries up to three allocations, times the call's first pass into each and keeps the
+ * fastest.  That call blocks the host until the measurement is done, holds up to 3x the workspace meanwhile and must not be
+ * made under stream capture; later calls are asynchronous as documented above. */
+int mi355fft_plan_set_workspace_placement(mi355fft_plan* plan, int on);
 /* Tunables (0 = library default): transforms per workspace chunk of the multi-pass path. */
 int mi355fft_plan_set_chunk_batch(mi355fft_plan* plan, size_t chunk_batch);
 /* Plan-owned HBM workspaces (one per stream the plan was used on, kept for reuse): bytes currently held, and a

@@ -434,6 +434,11 @@ int mi355fft_plan_fused_status(const mi355fft_plan* plan, void* stream, unsigned
         return hip_err(MI355FFT_ERR_HIP);
     return MI355FFT_OK;
 }
+int mi355fft_plan_set_workspace_placement(mi355fft_plan* plan, int on) {
+    if (!plan) return set_err(MI355FFT_ERR_INVALID_ARG, "null plan");
+    plan->p.place_workspace = on != 0;
+    return MI355FFT_OK;
+}
 int mi355fft_plan_set_chunk_batch(mi355fft_plan* plan, size_t chunk_batch) {
     if (!plan) return set_err(MI355FFT_ERR_INVALID_ARG, "null plan");
     plan->p.chunk_batch = chunk_batch;

@@ -538,7 +538,9 @@ static int append_general_passes(Plan& plan, size_t N, const std::vector<size_t>
     for (size_t p = 0; p < radices.size(); ++p) {
         const size_t R = radices[p];
         const KernelEntry* k = find_kernel(kinds[p], plan.prec, R);
-        // a prime tile height: Rader inside the tile (plain passes only: the fused Bluestein / Rader sequences use smooth heights)
+        // a prime tile height: Rader inside the tile.  Only PLAIN pass kinds can be prime tiles: the gather / multiply / scatter
+        // passes of the fused sequences exist for smooth heights only, but the plain passes in between them may be prime (the fused
+        // Rader takes its radices from choose_general_radices(p - 1): 41959 runs gather<42> -> k2rlater<37> -> rmul<27> | ...)
         const bool prime_tile = !k && (kinds[p] == KIND_K2G_FIRST || kinds[p] == KIND_K2G_LATER);
         if (prime_tile) k = find_kernel(kinds[p] == KIND_K2G_FIRST ? KIND_K2R_FIRST : KIND_K2R_LATER, plan.prec, R);
         if (!k) return MI355FFT_ERR_UNSUPPORTED;
@@ -1206,6 +1208,11 @@ size_t Plan::workspace_bytes() {
         std::lock_guard<std::mutex> g(s->launch_mutex);
         total += s->ws.bytes + s->pipe.ring.bytes;
     }
+    {  // staging buffers of the host-slice path: idle contexts and the ones lent to running calls
+        std::lock_guard<std::mutex> g(host_pool_mutex);
+        for (auto* pool : {&host_pool, &host_busy})
+            for (auto& c : *pool) total += c->in.bytes + c->out.bytes;
+    }
     return total + (inner ? inner->workspace_bytes() : 0);
 }
 // Releases every cached workspace (the map of slots stays).  Per slot: take the launch lock FIRST (no caller can enqueue a
@@ -1228,6 +1235,16 @@ size_t Plan::trim_workspaces() {
         backend::dfree(s->pipe.ring.ptr);
         s->ws = Workspace{};
         s->pipe.ring = Workspace{};
+    }
+    {  // idle staging contexts of the host-slice path (their last call has synchronised its streams before returning them)
+        std::lock_guard<std::mutex> g(host_pool_mutex);
+        for (auto& c : host_pool) {
+            freed += c->in.bytes + c->out.bytes;
+            backend::dfree(c->in.ptr);
+            backend::dfree(c->out.ptr);
+            c->in = Workspace{};
+            c->out = Workspace{};
+        }
     }
     return freed;
 }
@@ -1610,17 +1627,18 @@ template <class T> static int execute_t(Plan& plan, const void* in, void* out, s
         launch_lock = std::unique_lock<std::mutex>(slot.launch_mutex);
         ws = (char*)plan.workspace_in(slot, chunk * n * esz, stream);
         if (!ws) return MI355FFT_ERR_OUT_OF_MEMORY;
-        // Workspace placement.  Identical kernels on identical data run 3 - 4 % apart depending on WHICH device allocation the
-        // workspace is (measured in one process: eight plans of 2^20 x 1024, each with its own 8 GiB workspace, fall into two groups,
-        // 5.61 / 5.52 TB/s and 5.42 / 5.32, independent of the workspace's offset inside its allocation and of its distance to the
-        // caller's buffer: profiles/r3/ab_ws_offset_probe*.jsonl -- presumably how the driver could back the range physically).
-        // So a large workspace is chosen by measurement, once per (plan, stream, size): up to three allocations, the first pass
-        // of this very call timed into each (it reads the caller's input and overwrites the candidate, which the real run then
-        // does again), the fastest kept.  Costs three extra first passes on the first call of a plan.
-        if (!slot.ws.placed && mode == 0 && chunk * n * esz >= ((size_t)256 << 20) && tr == nullptr && !(plan.dbg & 4)) {
+        // Workspace placement (OPT-IN: mi355fft_plan_set_workspace_placement).  Identical kernels on identical data run 3 - 4 % apart
+        // depending on WHICH device allocation the workspace is (measured in one process: eight plans of 2^20 x 1024, each with its own
+        // 8 GiB workspace, fall into two groups, 5.61 / 5.52 TB/s and 5.42 / 5.32, independent of the workspace's offset inside its
+        // allocation and of its distance to the caller's buffer: profiles/r3/ab_ws_offset_probe*.jsonl).  With the option set, a large
+        // workspace is chosen by measurement once per (plan, stream, size): up to three allocations, the first pass of this very call
+        // timed into each, the fastest kept.  That first call BLOCKS the host, allocates up to 3x the workspace for its duration and
+        // cannot be captured into a graph -- which is why it is not the default behind an API documented as asynchronous.
+        if (plan.place_workspace && !slot.ws.placed && mode == 0 && chunk * n * esz >= ((size_t)256 << 20) && tr == nullptr && !(plan.dbg & 4)) {
             slot.ws.placed = true;
             const size_t bytes = chunk * n * esz, cb0 = std::min(chunk, batch);
             void* cand[3] = {slot.ws.ptr, backend::dmalloc(bytes), backend::dmalloc(bytes)};
+            if (!cand[1] || !cand[2]) backend::check_launch();  // a failed candidate allocation must not leave a sticky error for the next launch check
             float best_ms = 0;
             int best = 0;
             void *e0 = backend::event_create(), *e1 = backend::event_create();

@@ -90,6 +90,7 @@ struct Plan {
     std::vector<void*> device_allocs;
     size_t chunk_batch = 0;
     int dbg = 0;
+    bool place_workspace = false;  // opt-in workspace placement tournament (plan.cpp execute_t)
     // chunk pipeline (execute_pipelined): 0 = off (one full-size workspace), 1 = chunks through a cache-resident ring on the caller's
     // stream, 2 = the same with every pass but the last on side streams (passes of neighbouring chunks overlap)
     int pipe_mode = 0;

@@ -231,6 +231,10 @@ class Fft:
         n = self._lib.mi355fft_plan_num_kernels(self._h)
         return [self._lib.mi355fft_plan_kernel_name(self._h, i).decode() for i in range(n)]
 
+    def set_workspace_placement(self, on=True):
+        """Opt into the measured choice of the in-place workspace allocation (blocking first call, 3x transient memory)."""
+        self._check(self._lib.mi355fft_plan_set_workspace_placement(self._h, 1 if on else 0))
+
     def set_chunk_batch(self, chunk_batch):
         self._check(self._lib.mi355fft_plan_set_chunk_batch(self._h, int(chunk_batch)))
 

@@ -22,10 +22,15 @@ use std::sync::Arc;
 
 /// Raw bindings: one declaration per function of include/mi355fft.h.
 pub mod ffi {
-    use std::ffi::{c_int, c_void};
+    use std::ffi::{c_int, c_uint, c_void};
 
     #[repr(C)]
     pub struct Mi355Plan {
+        _private: [u8; 0],
+    }
+    /// `mi355fft_multi_plan`: one plan over several devices (batch rows sharded across them).
+    #[repr(C)]
+    pub struct Mi355MultiPlan {
         _private: [u8; 0],
     }
 
@@ -95,7 +100,26 @@ pub mod ffi {
         pub fn mi355fft_plan_num_kernels(plan: *const Mi355Plan) -> c_int;
         pub fn mi355fft_plan_kernel_name(plan: *const Mi355Plan, index: c_int) -> *const std::ffi::c_char;
         pub fn mi355fft_profile_inplace_dev(plan: *const Mi355Plan, buffer: *mut c_void, batch: usize, stream: *mut c_void, reps: c_int, ms_per_kernel: *mut f32, n_kernels: c_int) -> c_int;
+        pub fn mi355fft_multi_plan_create(len: usize, direction: c_int, precision: c_int, options: *const Mi355PlanOptions, devices: *const c_int, n_devices: c_int, out_plan: *mut *mut Mi355MultiPlan) -> c_int;
+        pub fn mi355fft_multi_plan_destroy(plan: *mut Mi355MultiPlan) -> c_int;
+        pub fn mi355fft_multi_plan_shards(plan: *const Mi355MultiPlan) -> c_int;
+        pub fn mi355fft_multi_plan_device(plan: *const Mi355MultiPlan, shard: c_int) -> c_int;
+        pub fn mi355fft_multi_plan_replica(plan: *const Mi355MultiPlan, shard: c_int) -> *const Mi355Plan;
+        pub fn mi355fft_shard_rows(batch: usize, n_shards: c_int, shard: c_int, first_row: *mut usize, rows: *mut usize) -> c_int;
+        pub fn mi355fft_multi_process_inplace_host(plan: *const Mi355MultiPlan, buffer: *mut c_void, n_elems: usize, scratch: *mut c_void, scratch_elems: usize) -> c_int;
+        pub fn mi355fft_multi_process_outofplace_host(plan: *const Mi355MultiPlan, input: *mut c_void, n_in: usize, output: *mut c_void, n_out: usize, scratch: *mut c_void, scratch_elems: usize) -> c_int;
+        pub fn mi355fft_multi_process_immutable_host(plan: *const Mi355MultiPlan, input: *const c_void, n_in: usize, output: *mut c_void, n_out: usize, scratch: *mut c_void, scratch_elems: usize) -> c_int;
+        pub fn mi355fft_multi_process_inplace_dev(plan: *const Mi355MultiPlan, buffers: *const *mut c_void, batch: usize, streams: *const *mut c_void) -> c_int;
+        pub fn mi355fft_multi_process_outofplace_dev(plan: *const Mi355MultiPlan, inputs: *const *mut c_void, outputs: *const *mut c_void, batch: usize, streams: *const *mut c_void) -> c_int;
+        pub fn mi355fft_multi_process_immutable_dev(plan: *const Mi355MultiPlan, inputs: *const *const c_void, outputs: *const *mut c_void, batch: usize, streams: *const *mut c_void) -> c_int;
+        pub fn mi355fft_multi_synchronize(plan: *const Mi355MultiPlan, streams: *const *mut c_void) -> c_int;
+        pub fn mi355fft_multi_scatter_dev(plan: *const Mi355MultiPlan, root_buffer: *const c_void, root_device: c_int, buffers: *const *mut c_void, batch: usize, streams: *const *mut c_void) -> c_int;
+        pub fn mi355fft_multi_gather_dev(plan: *const Mi355MultiPlan, buffers: *const *mut c_void, root_buffer: *mut c_void, root_device: c_int, batch: usize, streams: *const *mut c_void) -> c_int;
         pub fn mi355fft_measure_copy_ceiling(bytes: usize, gbps: *mut f64) -> c_int;
+        pub fn mi355fft_plan_set_fused(plan: *mut Mi355Plan, mode: c_int) -> c_int;
+        pub fn mi355fft_plan_is_fused(plan: *const Mi355Plan) -> c_int;
+        pub fn mi355fft_plan_fused_status(plan: *const Mi355Plan, stream: *mut c_void, error_word: *mut c_uint) -> c_int;
+        pub fn mi355fft_plan_set_workspace_placement(plan: *mut Mi355Plan, on: c_int) -> c_int;
         pub fn mi355fft_plan_set_chunk_batch(plan: *mut Mi355Plan, chunk_batch: usize) -> c_int;
         pub fn mi355fft_plan_workspace_bytes(plan: *const Mi355Plan) -> usize;
         pub fn mi355fft_plan_trim_workspaces(plan: *mut Mi355Plan, freed: *mut usize) -> c_int;
@@ -325,6 +349,121 @@ mod hip {
         }
     }
 
+    /// One planned transform over SEVERAL GPUs: the rows of every `process*` call are sharded across the devices (the chunk loop
+    /// of RustFFT's `validate_and_iter`, src/array_utils.rs:151-177, is the shard axis; no collective in the data path), each
+    /// device staging, transforming and copying back its own rows concurrently.  The call site does not change: this is still an
+    /// `Arc<dyn Fft<T>>`.
+    pub struct HipFftMulti<T> {
+        plan: *mut ffi::Mi355MultiPlan,
+        len: usize,
+        direction: FftDirection,
+        _marker: PhantomData<T>,
+    }
+    unsafe impl<T> Send for HipFftMulti<T> {}
+    unsafe impl<T> Sync for HipFftMulti<T> {}
+    impl<T> Drop for HipFftMulti<T> {
+        fn drop(&mut self) {
+            unsafe {
+                ffi::mi355fft_multi_plan_destroy(self.plan);
+            }
+        }
+    }
+    impl<T> Length for HipFftMulti<T> {
+        fn len(&self) -> usize {
+            self.len
+        }
+    }
+    impl<T> Direction for HipFftMulti<T> {
+        fn fft_direction(&self) -> FftDirection {
+            self.direction
+        }
+    }
+    impl<T> HipFftMulti<T> {
+        /// Number of shards (= entries of the device list) and the device of each.
+        pub fn shards(&self) -> usize {
+            unsafe { ffi::mi355fft_multi_plan_shards(self.plan) as usize }
+        }
+        pub fn device(&self, shard: usize) -> i32 {
+            unsafe { ffi::mi355fft_multi_plan_device(self.plan, shard as c_int) as i32 }
+        }
+        /// Rows `[first, first + rows)` of a batch of `batch` transforms that belong to `shard`.
+        pub fn shard_rows(&self, batch: usize, shard: usize) -> (usize, usize) {
+            let (mut first, mut rows) = (0usize, 0usize);
+            unsafe {
+                ffi::mi355fft_shard_rows(batch, self.shards() as c_int, shard as c_int, &mut first, &mut rows);
+            }
+            (first, rows)
+        }
+        /// In place on device-resident shards: `buffers[g]` holds shard g's rows in the memory of `device(g)`; asynchronous on
+        /// `streams[g]` (null entries / an empty slice: the devices' default streams).  `synchronize` waits for all of them.
+        pub unsafe fn process_device(&self, buffers: &[*mut c_void], batch: usize, streams: &[*mut c_void]) {
+            assert_eq!(buffers.len(), self.shards());
+            let st = if streams.is_empty() { std::ptr::null() } else { streams.as_ptr() };
+            let rc = ffi::mi355fft_multi_process_inplace_dev(self.plan, buffers.as_ptr(), batch, st);
+            if rc != 0 {
+                hip_panic(rc)
+            }
+        }
+        pub unsafe fn synchronize(&self, streams: &[*mut c_void]) {
+            let st = if streams.is_empty() { std::ptr::null() } else { streams.as_ptr() };
+            let rc = ffi::mi355fft_multi_synchronize(self.plan, st);
+            if rc != 0 {
+                hip_panic(rc)
+            }
+        }
+    }
+    impl<T: FftNum> Fft<T> for HipFftMulti<T> {
+        fn process_with_scratch(&self, buffer: &mut [Complex<T>], scratch: &mut [Complex<T>]) {
+            let rc = unsafe {
+                ffi::mi355fft_multi_process_inplace_host(self.plan, buffer.as_mut_ptr() as *mut c_void, buffer.len(), scratch.as_mut_ptr() as *mut c_void, scratch.len())
+            };
+            if rc != 0 {
+                hip_panic(rc)
+            }
+        }
+        fn process_outofplace_with_scratch(&self, input: &mut [Complex<T>], output: &mut [Complex<T>], scratch: &mut [Complex<T>]) {
+            let rc = unsafe {
+                ffi::mi355fft_multi_process_outofplace_host(
+                    self.plan,
+                    input.as_mut_ptr() as *mut c_void,
+                    input.len(),
+                    output.as_mut_ptr() as *mut c_void,
+                    output.len(),
+                    scratch.as_mut_ptr() as *mut c_void,
+                    scratch.len(),
+                )
+            };
+            if rc != 0 {
+                hip_panic(rc)
+            }
+        }
+        fn process_immutable_with_scratch(&self, input: &[Complex<T>], output: &mut [Complex<T>], scratch: &mut [Complex<T>]) {
+            let rc = unsafe {
+                ffi::mi355fft_multi_process_immutable_host(
+                    self.plan,
+                    input.as_ptr() as *const c_void,
+                    input.len(),
+                    output.as_mut_ptr() as *mut c_void,
+                    output.len(),
+                    scratch.as_mut_ptr() as *mut c_void,
+                    scratch.len(),
+                )
+            };
+            if rc != 0 {
+                hip_panic(rc)
+            }
+        }
+        fn get_inplace_scratch_len(&self) -> usize {
+            0
+        }
+        fn get_outofplace_scratch_len(&self) -> usize {
+            0
+        }
+        fn get_immutable_scratch_len(&self) -> usize {
+            0
+        }
+    }
+
     /// What the host planner keeps in charge of when it plans through `plan_fft_with`.
     pub struct HostPlannerOptions<'a, T> {
         /// the planner's whole recipe for this length; the GPU takes the family, the six-step split and the Bluestein
@@ -361,6 +500,8 @@ mod hip {
         cache: HashMap<(usize, bool), Arc<dyn Fft<T>>>,
         precision: c_int,
         fallback: rustfft::FftPlanner<T>,
+        /// devices the plans shard their batch rows over (more than one entry: `HipFftMulti`)
+        devices: Vec<c_int>,
     }
 
     impl<T: FftNum> FftPlannerHip<T> {
@@ -370,7 +511,29 @@ mod hip {
             if unsafe { ffi::mi355fft_device_count() } <= 0 || unsafe { ffi::mi355fft_init(0) } != 0 {
                 return Err(());
             }
-            Ok(Self { cache: HashMap::new(), precision, fallback: rustfft::FftPlanner::new() })
+            // every visible gfx950 device: with more than one, plans shard their batch rows across all of them
+            let devices: Vec<c_int> = (0..unsafe { ffi::mi355fft_device_count() }).collect();
+            Ok(Self { cache: HashMap::new(), precision, fallback: rustfft::FftPlanner::new(), devices })
+        }
+        /// The same over an explicit device list (an ordinal may repeat: each entry is one shard).
+        pub fn with_devices(devices: &[i32]) -> Result<Self, ()> {
+            let mut p = Self::new()?;
+            let visible = unsafe { ffi::mi355fft_device_count() };
+            if devices.is_empty() || devices.iter().any(|&d| d < 0 || d >= visible as i32) {
+                return Err(());
+            }
+            p.devices = devices.iter().map(|&d| d as c_int).collect();
+            Ok(p)
+        }
+        fn create_multi(&self, len: usize, direction: FftDirection) -> Result<HipFftMulti<T>, i32> {
+            let mut plan: *mut ffi::Mi355MultiPlan = std::ptr::null_mut();
+            let rc = unsafe {
+                ffi::mi355fft_multi_plan_create(len, direction_code(direction), self.precision, std::ptr::null(), self.devices.as_ptr(), self.devices.len() as c_int, &mut plan)
+            };
+            if rc != 0 {
+                return Err(rc as i32);
+            }
+            Ok(HipFftMulti { plan, len, direction, _marker: PhantomData })
         }
 
         /// One `Arc` per (len, direction), like RustFFT's planner cache.
@@ -379,10 +542,17 @@ mod hip {
             if let Some(fft) = self.cache.get(&key) {
                 return Arc::clone(fft);
             }
-            let fft: Arc<dyn Fft<T>> = match self.create(len, direction, std::ptr::null()) {
-                Ok(gpu) => Arc::new(gpu),
-                // MI355FFT_ERR_UNSUPPORTED: no GPU plan for this length in this build -> the CPU planner serves it
-                Err(_) => self.fallback.plan_fft(len, direction),
+            let planned: Result<Arc<dyn Fft<T>>, i32> = if self.devices.len() > 1 {
+                self.create_multi(len, direction).map(|gpu| Arc::new(gpu) as Arc<dyn Fft<T>>)
+            } else {
+                self.create(len, direction, std::ptr::null()).map(|gpu| Arc::new(gpu) as Arc<dyn Fft<T>>)
+            };
+            let fft: Arc<dyn Fft<T>> = match planned {
+                Ok(gpu) => gpu,
+                // MI355FFT_ERR_UNSUPPORTED only: no GPU plan for this length in this build -> the CPU planner serves it
+                Err(rc) if rc == ffi::ERR_UNSUPPORTED as i32 => self.fallback.plan_fft(len, direction),
+                // anything else (out of memory, a HIP failure, an invalid argument) is a real error: a silent CPU plan would hide it
+                Err(rc) => panic!("mi355fft_plan_create failed for len {}: {}", len, strerror(rc)),
             };
             self.cache.insert(key, Arc::clone(&fft));
             fft
@@ -456,7 +626,7 @@ mod hip {
 }
 
 #[cfg(feature = "link")]
-pub use hip::{strerror, version, FftPlannerHip, HipFft, HostPlannerOptions};
+pub use hip::{strerror, version, FftPlannerHip, HipFft, HipFftMulti, HostPlannerOptions};
 
 /// Without the `link` feature the crate is the stub RustFFT uses for a disabled back-end: the planner type exists and
 /// its constructor reports that the hardware is unavailable.

@@ -732,7 +732,7 @@ def test_large_primes_vs_oracle(planners, oracle, dtype):
     raders_algorithm.rs:302-322 tests 112501 / 216569 / 417623 the same way): all four API modes against the oracle's plan and
     numpy complex128, both directions."""
     planner = planners[np.dtype(dtype)]
-    for p in (12289, 40961, 65537, 112501):
+    for p in (12289, 40961, 41959, 65537, 112501):  # 41959 - 1 = 2 * 3^4 * 7 * 37: a PRIME tile height (37) between the fused passes
         for d in (0, 1):
             fft = planner.plan_fft(p, d)
             # round 3: multi-kernel Rader (gather / spectrum multiply / scatter fused into the column-tile passes of the two
@@ -790,7 +790,9 @@ def test_host_slices_pipeline_and_shared_plan_threads(planners, oracle):
         assert rel_l2(y[r * n:(r + 1) * n], want) < REL[np.dtype(np.complex64)], r
     small = x[: 8 * n].copy()
     fft.process(small)  # one chunk
-    assert np.array_equal(small, y[: 8 * n])
+    # (2^16 runs the fused two-pass launch for batches that fill its ring and two launches below that: the same kernel bodies
+    # compiled into two kernels, equal up to the rounding of differently contracted multiply-adds)
+    assert np.array_equal(small, y[: 8 * n]) if not fft.is_fused() else rel_l2(small, y[: 8 * n]) < 2e-7
     out = np.zeros_like(x)
     fft.process_immutable_with_scratch(x, out)
     assert np.array_equal(out, y)
@@ -850,6 +852,219 @@ def test_config2_full_batch_every_row(planners):
             got = y[r * n:(r + 1) * n].cpu().numpy()
             assert rel_l2(got, numpy_fft(keep[r], n, d == 1)) < REL[np.dtype(np.complex64)], (d, r)
         del y
+
+
+# ---- round 4 ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("p", [216569, 417623])
+def test_reference_overflow_regression_primes(planners, oracle, p):
+    """raders_algorithm.rs:312-322: the reference's regression test for 32-bit overflow in the index arithmetic runs 112501,
+    216569 and 417623.  216568 = 2^3 * 11 * 23 * 107 and 417622 = 2 * 208811 have prime factors above 31, so the GPU plans them
+    through the fused multi-kernel Bluestein (element indices up to batch * M, chirp exponents i^2 mod 2p up to 1.7e11 computed
+    on the host in 128 bits): both directions, against the oracle's plan and numpy complex128."""
+    for dtype in (np.complex64, np.complex128):
+        planner = planners[np.dtype(dtype)]
+        for d in (0, 1):
+            fft = planner.plan_fft(p, d)
+            x = zero_mean_signal(p * 3, dtype, seed=p + d)
+            y = x.copy()
+            fft.process(y)
+            assert rel_l2(y, numpy_fft(x, p, d == 1)) < REL[np.dtype(dtype)], (p, d, fft.describe())
+            want = x[:p].copy()
+            oracle.plan(dtype, p, d).process(want)
+            assert compare_vectors(want, y[:p]), (p, d)
+
+
+def test_pow2_above_2p24(planners):
+    """One length above north_star's range: 2^25 Complex<f32> (three passes, 256 MiB per row), two rows, against numpy
+    complex128 -- the claim "three column-tile passes up to 2^30" is tested at least one step past 2^24."""
+    import torch
+
+    n = 1 << 25
+    fft = planners[np.dtype(np.complex64)].plan_fft_forward(n)
+    assert fft.describe().count("k2") == 3, fft.describe()
+    x = zero_mean_signal(n * 2, np.complex64, seed=25)
+    y = torch.from_numpy(x).cuda()
+    fft.process(y)
+    torch.cuda.synchronize()
+    assert rel_l2(y.cpu().numpy(), numpy_fft(x, n, False)) < REL[np.dtype(np.complex64)]
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_host_slices_need_only_element_alignment_on_device(planners, oracle, dtype):
+    """A Rust `&mut [Complex<T>]` guarantees align_of::<T>() only (4 bytes for Complex<f32>, 8 for Complex<f64>; SURVEY section
+    8(b) layout rule): host buffers that start one float past a 16-byte boundary, all three trait methods, single-kernel,
+    fused and multi-pass plans, on the real device (the staging copies are plain byte copies)."""
+    real = np.float32 if dtype == np.complex64 else np.float64
+    planner = planners[np.dtype(dtype)]
+    for n, rows in ((1009, 3), (1200, 3), (1 << 16, 3), (1 << 20, 12)):
+        for d in (0, 1):
+            fft = planner.plan_fft(n, d)
+            x = random_signal(rows * n, dtype, seed=n + d)
+            want = x[:n].copy()
+            oracle.plan(dtype, n, d).process(want)
+
+            def skewed(values=None):
+                raw = np.zeros(2 * rows * n + 8, dtype=real)
+                start = ((-raw.ctypes.data) % 16) // raw.itemsize + 1
+                view = raw[start:start + 2 * rows * n].view(dtype)
+                assert view.ctypes.data % 16 == raw.itemsize and view.flags.c_contiguous
+                if values is not None:
+                    view[:] = values
+                return view
+
+            a = skewed(x)
+            fft.process(a)
+            assert compare_vectors(want, a[:n]), (n, d, "in place")
+            assert rel_l2(a, numpy_fft(x, n, d == 1)) < REL[np.dtype(dtype)], (n, d)
+            src, dst = skewed(x), skewed()
+            fft.process_outofplace_with_scratch(src, dst)
+            assert rel_l2(dst, a) < 1e-6, (n, d, "out of place")
+            src, dst = skewed(x), skewed()
+            fft.process_immutable_with_scratch(src, dst)
+            assert rel_l2(dst, a) < 1e-6 and np.array_equal(src, x), (n, d, "immutable")
+
+
+@pytest.mark.parametrize("log2n", [16, 17, 18, 19, 20, 21, 22])
+def test_fused_two_pass_kernel_vs_oracle(planners, oracle, log2n):
+    """The fused two-pass launch (one kernel, second pass of transform g - lag beside the first pass of transform g, the
+    intermediate through a cache-resident ring; launch.h k2f_kernel) for every length that has one: rows across the whole batch
+    against the oracle's Radix4 (src/algorithm/radix4.rs:167-203), the whole batch against the two-launch plan of the same
+    kernels, the dependency error word, all three device entry points, both directions."""
+    import torch
+
+    import rustfft_amd
+
+    n = 1 << log2n
+    batch = max(24, (1 << 28) >> log2n)  # 2 GiB of rows (at least 24 transforms: more than any ring has slots)
+    planner = rustfft_amd.FftPlanner(np.complex64)  # own planner: the plans' fused setting is changed below
+    x = torch.empty(batch * n, dtype=torch.complex64, device="cuda")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1000 + log2n)
+    torch.view_as_real(x).uniform_(0.0, 10.0, generator=g)
+    rows = sorted({0, 1, batch // 2, batch - 1})
+    for d in (0, 1):
+        fus, two = planner.plan_fft(n, d), rustfft_amd.FftPlanner(np.complex64).plan_fft(n, d)
+        fus.set_fused(1)
+        two.set_fused(0)
+        assert fus.is_fused() and fus.describe().startswith("fused{") and not two.is_fused(), fus.describe()
+        a, b = x.clone(), x.clone()
+        two.process(a)
+        fus.process(b)
+        assert fus.fused_status() == 0
+        # the same kernel bodies, compiled into another kernel: equal up to the rounding of differently contracted multiply-adds
+        err = (torch.view_as_real(a) - torch.view_as_real(b)).abs().max().item()
+        assert err <= 4e-7 * torch.view_as_real(a).abs().max().item(), (log2n, d, err)
+        ref = oracle.plan(np.complex64, n, d)
+        for r in rows:
+            want = x[r * n:(r + 1) * n].cpu().numpy()
+            ref.process(want)
+            assert compare_vectors(want, b[r * n:(r + 1) * n].cpu().numpy()), (log2n, d, r)
+        out = torch.empty_like(x)
+        fus.process_immutable_with_scratch(x, out)
+        assert torch.equal(torch.view_as_real(out), torch.view_as_real(b)), (log2n, d, "immutable")
+        src = x.clone()
+        fus.process_outofplace_with_scratch(src, out)
+        assert torch.equal(torch.view_as_real(out), torch.view_as_real(b)) and fus.fused_status() == 0, (log2n, d, "out of place")
+        # a batch smaller than the ring runs as two launches: identical to the two-launch plan
+        c, e = x[: 2 * n].clone(), x[: 2 * n].clone()
+        fus.process(c)
+        two.process(e)
+        assert torch.equal(torch.view_as_real(c), torch.view_as_real(e)), (log2n, d, "small batch")
+
+
+def test_fused_kernel_repeatable_under_load_and_across_streams(planners):
+    """A stale read of the ring (a missing acquire, a slot rewritten too early) shows up as a run-to-run difference long before it
+    breaks a tolerance: 30 fused transforms of one input, odd ones beside a copy stream that hammers HBM, must agree bit for
+    bit; then two host threads drive the same plan on their own streams (own rings) concurrently."""
+    import torch
+
+    import rustfft_amd
+
+    n, batch = 1 << 20, 256
+    fft = rustfft_amd.FftPlanner(np.complex64).plan_fft_forward(n)
+    assert fft.is_fused()
+    x = torch.empty(batch * n, dtype=torch.complex64, device="cuda")
+    torch.view_as_real(x).uniform_(-1.0, 1.0)
+    side = torch.cuda.Stream()
+    first = None
+    for r in range(30):
+        y = x.clone()
+        if r % 2:
+            with torch.cuda.stream(side):
+                z = x.clone()  # noqa: F841
+        fft.process(y)
+        assert fft.fused_status() == 0
+        if first is None:
+            first = y
+        else:
+            assert torch.equal(torch.view_as_real(first), torch.view_as_real(y)), r
+    results, errors = [None, None], []
+
+    def worker(i):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                y = x.clone()
+                for _ in range(3):
+                    y.copy_(x)
+                    fft.process(y)
+                assert fft.fused_status() == 0
+                s.synchronize()
+                results[i] = y
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for y in results:
+        assert torch.equal(torch.view_as_real(first), torch.view_as_real(y))
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_multi_device_plan_on_one_gpu(planners, oracle, dtype):
+    """mi355fft_multi_plan with the device list [0, 0] (two shards, two replicas, two worker threads and staging pools on the one
+    GPU of this box): the three trait methods on host slices and on device-resident shards against the oracle, ragged batches,
+    the scatter / gather edges, the validation semantics."""
+    import torch
+
+    import rustfft_amd
+    from rustfft_amd import FftPanic
+
+    mp = rustfft_amd.FftPlannerHipMulti(dtype, devices=[0, 0])
+    for n, batch in ((1009, 7), (1200, 5), (1 << 16, 5), (1 << 20, 25)):
+        for d in (0, 1):
+            multi = mp.plan_fft(n, d)
+            assert multi.shards() == 2 and multi.devices() == [0, 0]
+            x = random_signal(n * batch, dtype, seed=n + d)
+            ref = oracle.plan(dtype, n, d)
+            a = x.copy()
+            multi.process(a)
+            for r in (0, batch // 2, batch - 1):
+                want = x[r * n:(r + 1) * n].copy()
+                ref.process(want)
+                assert compare_vectors(want, a[r * n:(r + 1) * n]), (n, d, r)
+            assert rel_l2(a, numpy_fft(x, n, d == 1)) < REL[np.dtype(dtype)], (n, d)
+            y = np.empty_like(x)
+            multi.process_immutable_with_scratch(x, y)
+            assert rel_l2(y, a) < 1e-6
+            # device-resident shards + the edges
+            root = torch.from_numpy(x).cuda()
+            shards = [torch.empty(multi.shard_rows(batch, g)[1] * n, dtype=root.dtype, device="cuda") for g in range(2)]
+            multi.scatter(root, shards)
+            multi.process(shards)
+            out = torch.empty_like(root)
+            multi.gather(shards, out)
+            multi.synchronize()
+            assert rel_l2(out.cpu().numpy(), a) < 1e-6, (n, d, "device shards")
+    multi = mp.plan_fft(1024, 0)
+    with pytest.raises(FftPanic, match="multiple of FFT length"):
+        multi.process(random_signal(1024 * 3 + 1, dtype))
+    with pytest.raises(FftPanic, match="same length"):
+        multi.process_outofplace_with_scratch(random_signal(1024, dtype), np.empty(2048, dtype))
 
 
 def test_bench_two_ranks_on_one_gpu():

@@ -16,6 +16,9 @@ C_TO_RUST = {
     "double*": "*mut f64", "size_t*": "*mut usize",
     "mi355fft_twiddle_fn": "Option<extern \"C\" fn(*mut c_void, usize, usize, *mut f64, *mut f64)>",
     "const mi355fft_recipe_node*": "*const Mi355RecipeNode", "float*": "*mut f32",
+    # round 4: the multi-device plan and the fused-launch hooks
+    "mi355fft_multi_plan**": "*mut *mut Mi355MultiPlan", "mi355fft_multi_plan*": "*mut Mi355MultiPlan", "const mi355fft_multi_plan*": "*const Mi355MultiPlan",
+    "const int*": "*const c_int", "void*const*": "*const *mut c_void", "const void*const*": "*const *const c_void", "unsigned*": "*mut c_uint",
 }
 
 
@@ -150,3 +153,65 @@ def test_crate_layout():
         assert os.path.isfile(os.path.join(CRATE, rel)), rel
     manifest = open(os.path.join(CRATE, "Cargo.toml")).read()
     assert re.search(r'^rustfft\s*=', manifest, flags=re.M) and "[features]" in manifest
+
+
+def _split_args(text):
+    args, depth, cur = [], 0, ""
+    for ch in text:
+        if ch in "(<[":
+            depth += 1
+        elif ch in ")>]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            args.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        args.append(cur.strip())
+    return args
+
+
+def test_crate_call_sites_pass_the_arguments_in_the_headers_order():
+    """Declarations that match the header are not enough: a call site can still swap two arguments of the same type (input and
+    output pointers, or a length with the other buffer's).  Every trait method of `impl Fft<T>` (one-device and multi-device
+    object) must call ITS entry point -- process_with_scratch -> *_inplace_host, process_outofplace_with_scratch ->
+    *_outofplace_host, process_immutable_with_scratch -> *_immutable_host -- with (plan, pointer of X, X.len(), ...) in the order
+    of the header's parameter list, const-ness of the pointer included."""
+    header = open(os.path.join(ROOT, "include", "mi355fft.h")).read()
+    protos = c_prototypes(header)
+    src = re.sub(r"//[^\n]*", "", open(os.path.join(CRATE, "src", "lib.rs")).read())
+    want = {
+        "process_with_scratch": ("inplace", [("plan",), ("mut", "buffer"), ("len", "buffer"), ("mut", "scratch"), ("len", "scratch")]),
+        "process_outofplace_with_scratch": ("outofplace", [("plan",), ("mut", "input"), ("len", "input"), ("mut", "output"), ("len", "output"), ("mut", "scratch"), ("len", "scratch")]),
+        "process_immutable_with_scratch": ("immutable", [("plan",), ("const", "input"), ("len", "input"), ("mut", "output"), ("len", "output"), ("mut", "scratch"), ("len", "scratch")]),
+    }
+    checked = 0
+    for impl_for, prefix in (("HipFft", "mi355fft_process_"), ("HipFftMulti", "mi355fft_multi_process_")):
+        body = re.search(r"impl<T: FftNum> Fft<T> for %s<T> \{(.*?)\n    \}\n" % impl_for, src, flags=re.S).group(1)
+        for method, (mode, roles) in want.items():
+            fn_body = re.search(r"fn %s\(.*?\) \{(.*?)\n        \}" % method, body, flags=re.S).group(1)
+            calls = re.findall(r"ffi::(mi355fft_\w+)\s*\((.*?)\)\s*\n?\s*\};", fn_body, flags=re.S)
+            assert len(calls) == 1, (impl_for, method, calls)
+            name, argtext = calls[0]
+            assert name == prefix + mode + "_host", (impl_for, method, name)
+            args = _split_args(argtext)
+            cparams = protos[name][1]
+            assert len(args) == len(cparams) == len(roles), (name, args, cparams)
+            for arg, role, ctype in zip(args, roles, cparams):
+                if role[0] == "plan":
+                    assert arg == "self.plan", (name, arg)
+                elif role[0] == "len":
+                    assert arg == role[1] + ".len()" and ctype == "size_t", (name, arg, ctype)
+                elif role[0] == "mut":
+                    assert arg == role[1] + ".as_mut_ptr() as *mut c_void" and ctype == "void*", (name, arg, ctype)
+                else:
+                    assert arg == role[1] + ".as_ptr() as *const c_void" and ctype == "const void*", (name, arg, ctype)
+            checked += 1
+    assert checked == 6
+    # the header's own parameter NAMES carry the same order (buffer / n_elems; input, n_in, output, n_out)
+    flat = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    for name in ("mi355fft_process_outofplace_host", "mi355fft_multi_process_outofplace_host", "mi355fft_process_immutable_host", "mi355fft_multi_process_immutable_host"):
+        params = re.search(name + r"\s*\((.*?)\)\s*;", flat, flags=re.S).group(1)
+        names = [re.sub(r"\s+", " ", a).strip().split(" ")[-1].lstrip("*") for a in params.split(",")]
+        assert names == ["plan", "input", "n_in", "output", "n_out", "scratch", "scratch_elems"], (name, names)

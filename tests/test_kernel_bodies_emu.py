@@ -298,7 +298,8 @@ def test_large_prime_rader(emu_planner, oracle, dtype):
     import rustfft_amd
 
     planner = emu_planner(dtype)
-    for p, algo in ((4481, rustfft_amd.ALGO_RADER), (12289, rustfft_amd.ALGO_AUTO), (40961, rustfft_amd.ALGO_AUTO), (65537, rustfft_amd.ALGO_RADER)):
+    for p, algo in ((4481, rustfft_amd.ALGO_RADER), (12289, rustfft_amd.ALGO_AUTO), (40961, rustfft_amd.ALGO_AUTO), (41959, rustfft_amd.ALGO_AUTO), (65537, rustfft_amd.ALGO_RADER)):
+        # (41959 - 1 = 2 * 3^4 * 7 * 37: a PRIME tile height, Rader inside the tile, between the fused gather / multiply passes)
         for d in (0, 1):
             fft = planner.plan_fft_with(p, d, algorithm=algo)
             assert fft.describe().startswith("rader_large(p-1=%d fused: k2gfirst_gather<" % (p - 1)), fft.describe()
