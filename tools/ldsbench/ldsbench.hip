@@ -87,6 +87,27 @@ int main(int argc, char** argv) {
             pats.push_back({names[ni++], op, off, tile(P, d)});
         }
     }
+    // `ldsbench <waves> brief`: a short, labelled pattern list (one dispatch per line, in order) for a run under the SQ LDS
+    // counters (tools/r4/lds_counter_probe.py): known conflict-free / 2-way / 4-way patterns and the column-tile exchange ones
+    if (argc > 2 && !strcmp(argv[2], "brief")) {
+        std::vector<Pat> b;
+        for (int op : {RD32, WR32, RD64, WR64}) for (int s : {1, 2, 4, 8}) b.push_back({"lane*s", op, (op == RD64 || op == WR64) ? 2 * s : s, lin((op == RD64 || op == WR64) ? 2 * s : s)});
+        for (int op : {RD2, WR2}) for (int d : {1, 8}) for (int off : {1, 8, 33}) {
+            static char names[64][48];
+            static int ni = 0;
+            snprintf(names[ni], 48, "tile P=1058 d=%d", d);
+            b.push_back({names[ni++], op, off, tile(1058, d)});
+        }
+        // the staged twiddle-table reads of the column tiles: the 16 lanes of a column group read ONE 8-byte entry (broadcast), the
+        // wave's four row slots four consecutive entries (sub-pass 1: stride 1 entry) or entries 8 apart
+        auto bc = [](int stride_dw) { std::vector<unsigned> v(64); for (int l = 0; l < 64; ++l) v[l] = (l / 16) * stride_dw; return v; };
+        b.push_back({"bcast16 x4 +1e", RD64, 2, bc(2)});
+        b.push_back({"bcast16 x4 +8e", RD64, 16, bc(16)});
+        b.push_back({"bcast16 x4 +32e", RD64, 64, bc(64)});
+        b.push_back({"bcast16 x4 b32", RD32, 1, bc(1)});
+        b.push_back({"bcast64", RD64, 0, bc(0)});
+        pats = b;
+    }
     printf("%-16s %-22s %6s %10s\n", "op", "pattern", "off1/s", "cyc/instr");
     for (auto& p : pats) {
         kern_t k = nullptr;
