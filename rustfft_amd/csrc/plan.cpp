@@ -38,6 +38,16 @@ void ensure_registry() {
         register_bs57_f32(r);
         register_np2_f64(r);
         register_bs57_f64(r);  // `make tuning-min`: power-of-two kernels + the f32 Rader / Bluestein unit (kernel experiments that need a one-minute build)
+#if defined(MI355_MINIMAL_RADER)  // the emulator's tuning build: also the compiled Rader bodies (a variant is chosen per prime that HAS a default body)
+        register_rader_f32_0(r);
+        register_rader_f32_1(r);
+        register_rader_f32_2(r);
+        register_rader_f32_3(r);
+        register_rader_f64_0(r);
+        register_rader_f64_1(r);
+        register_rader_f64_2(r);
+        register_rader_f64_3(r);
+#endif
         return;
 #endif
 #if !defined(MI355_MINIMAL)

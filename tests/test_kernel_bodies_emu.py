@@ -24,6 +24,18 @@ def emu_planner():
     return lambda dtype: rustfft_amd.FftPlannerHip(dtype, lib=lib)
 
 
+@pytest.fixture(scope="module")
+def emu_tuning_planner():
+    """The small tuning build of the emulator (`make -C tests/emu tuning`: power-of-two, Rader and Bluestein units with their
+    tuning variants) for the tests that select a variant by number; every other test runs the SHIPPED registry."""
+    subprocess.check_call(["make", "-C", EMU_DIR, "-j", "8", "-s", "tuning"])
+    import rustfft_amd
+    from rustfft_amd import _native
+
+    lib = _native.load(os.path.join(EMU_DIR, "libmi355fft_emu_tuning.so"))
+    return lambda dtype: rustfft_amd.FftPlannerHip(dtype, lib=lib)
+
+
 POW2_SINGLE = [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096]
 POW2_MULTI = [1 << 16, 1 << 17, 1 << 18, 1 << 19]  # 2^13 .. 2^15 are single split-exchange kernels (test_single_kernel_above_4096)
 
@@ -635,13 +647,13 @@ def test_prime_radices_17_to_31(emu_planner, oracle, dtype):
     assert "bluestein" in planner.plan_fft(4913, 0).describe()  # 17^3: three 17-point sub-passes need 289 threads per row
 
 
-def test_pair_fused_column_tiles(emu_planner, oracle):
+def test_pair_fused_column_tiles(emu_tuning_planner, oracle):
     """engine.h pair-fused sub-passes (first LDS exchange replaced by a lane-pair register exchange): the emulator's
     executor swaps the register slots of threads t and t + 32 exactly as v_permlane32_swap does.  Selected here through the
-    tuning variant number (the emulator is a tuning build)."""
+    tuning variant number (the emulator's tuning build)."""
     os.environ["MI355FFT_VARIANT"] = "12"
     try:
-        planner = emu_planner(np.complex64)
+        planner = emu_tuning_planner(np.complex64)
         for n in (1 << 18, 1 << 19, 1 << 20):
             for d in (0, 1):
                 fft = planner.plan_fft(n, d)
@@ -652,7 +664,7 @@ def test_pair_fused_column_tiles(emu_planner, oracle):
 
 
 @pytest.mark.parametrize("order", ["forward", "reverse"])
-def test_rader_register_handover(emu_planner, oracle, order):
+def test_rader_register_handover(emu_tuning_planner, oracle, order):
     """kernels.h rader_body MODE 5: the side-by-side Rader body whose second inner transform runs the reversed schedule, so the
     d[] multiply and the x[0] / X[0] step (raders_algorithm.rs:256-262) happen in registers and the spectrum never goes
     through LDS.  Primes of every schedule shape (two to four sub-passes, padded and unpadded layouts, different row pitches
@@ -666,7 +678,7 @@ def test_rader_register_handover(emu_planner, oracle, order):
         for variant, primes in (("5", (97, 193, 271, 1009, 4057)), ("6", (193, 541, 1009, 4051))):
             os.environ["MI355FFT_VARIANT"] = variant
             for dtype in (np.complex64, np.complex128):
-                planner = emu_planner(dtype)
+                planner = emu_tuning_planner(dtype)
                 for p in primes:
                     for d in (0, 1):
                         fft = planner.plan_fft(p, d)
@@ -682,7 +694,7 @@ def test_rader_register_handover(emu_planner, oracle, order):
 
 
 @pytest.mark.parametrize("order", ["forward", "reverse"])
-def test_two_columns_per_lane_tiles(emu_planner, oracle, order):
+def test_two_columns_per_lane_tiles(emu_tuning_planner, oracle, order):
     """Tuning variants 50 - 53 of the column tiles (launch.h DevExecPair, kernels.h k2_body ABL bit 4096): two virtual threads --
     adjacent columns of the same rows -- per physical thread, the even one moving both columns' rows as 16-byte accesses.  The
     emulator runs the virtual threads as ordinary threads (their register arrays are adjacent exactly as on the device), so this
@@ -694,7 +706,7 @@ def test_two_columns_per_lane_tiles(emu_planner, oracle, order):
         for variant, n, tag in (("50", 1 << 20, "1024, 64, 8, 8, 16"), ("51", 1 << 20, "1024, 64, 16, 8, 8"), ("52", 1 << 22, "2048, 128, 8, 16, 16"),
                                 ("53", 1 << 21, "2048, 128, 16, 16, 8")):
             os.environ["MI355FFT_VARIANT"] = variant
-            planner = emu_planner(np.complex64)  # (a planner caches its plans per length: one per variant)
+            planner = emu_tuning_planner(np.complex64)  # (a planner caches its plans per length: one per variant)
             for d in (0, 1):
                 fft = planner.plan_fft(n, d)
                 assert fft.describe().count(tag) >= 1 and "abl4" in fft.describe(), (variant, fft.describe())

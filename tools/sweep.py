@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--sizes", default="", help="comma-separated explicit lengths (overrides --min/--max)")
     ap.add_argument("--check", action="store_true", help="relative L2 error of row 0 against numpy complex128")
+    ap.add_argument("--fused", type=int, default=-1, help="fused two-pass launch: -1 the planner's choice, 0 never, 1 whenever compiled")
     ap.add_argument("--lib", default="", help="A/B runs: load this build of libmi355fft.so instead of rustfft_amd/lib's")
     args = ap.parse_args()
     import numpy as np
@@ -42,6 +43,8 @@ def main():
         torch.view_as_real(x).uniform_(-1.0, 1.0)
         fft = planner.plan_fft_forward(n)
         fft.set_chunk_batch(args.chunk)
+        if args.fused >= 0:
+            fft.set_fused(args.fused)
         err = None
         if args.check:
             x0 = x[:n].cpu().numpy()
@@ -63,7 +66,10 @@ def main():
         alg = batch * 2 * n * esz
         print(json.dumps({"n": n, "log2n": round(p, 3), "batch": batch, "ms": round(ms, 4), "gflops": round(batch * 5.0 * n * p / ms / 1e6, 1),
                           "alg_GBps": round(alg / ms / 1e6, 1), "kernel_ms": [round(k, 4) for k in kms],
-                          "kernel_GBps": [round(alg / k / 1e6, 1) if k > 0 else None for k in kms], "plan": fft.describe(), **({"rel_l2": err} if err is not None else {})}), flush=True)
+                          "kernel_GBps": [round(alg / k / 1e6, 1) if k > 0 else None for k in kms], "plan": fft.describe(), "fused": fft.is_fused(),
+                          # a fused plan runs ONE launch (`ms`); kernel_ms are its two passes as separate launches (event-bracketed), for comparison
+                          **({"fused_per_pass_equivalent_GBps": round(2 * alg / ms / 1e6, 1), "fused_error_word": fft.fused_status()} if fft.is_fused() else {}),
+                          **({"rel_l2": err} if err is not None else {})}), flush=True)
         del x
 
 
