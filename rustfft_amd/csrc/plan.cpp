@@ -1472,9 +1472,9 @@ template <class T> static int execute_pipelined(Plan& plan, const void* in, void
 // Both passes of a two-pass power-of-two plan in ONE launch (launch.h k2f_kernel): pass 2 of transform g - lag runs beside
 // pass 1 of transform g, the intermediate goes through a ring of `ns` transform-sized slots that stays in the Infinity Cache
 // (HBM sees one read and one write per transform), and there is no launch boundary at which the chip drains.  lag and ns follow
-// from how many transforms are in flight: F = ceil(workgroups the chip holds / tiles per step); lag = F + 1 steps (the first-pass
-// tiles of a transform have retired when its second-pass tiles come up), ns = lag + F + 1 slots (a slot is not rewritten while a
-// resident second-pass tile can still read it -- the counters enforce it; the slack only keeps anybody from waiting).
+// from how many transforms are in flight: F = ceil(workgroups the chip holds / tiles per step); lag = 2 F steps (the first-pass
+// tiles of a transform have long retired when its second-pass tiles come up), ns = 2 lag slots, at most 128 MiB (a slot is not
+// rewritten while a resident second-pass tile can still read it -- the counters enforce it; the slack only keeps anybody from waiting).
 template <class T> static int execute_fused(Plan& plan, const void* in, void* out, size_t batch, void* stream) {
     const KernelEntry& k = *plan.fused;
     const size_t esz = 2 * sizeof(T), n = plan.len;
@@ -1484,8 +1484,12 @@ template <class T> static int execute_fused(Plan& plan, const void* in, void* ou
     const int t0 = (int)fp.pass[0].tiles_per_fft, t1 = (int)fp.pass[1].tiles_per_fft;
     const int resident = 256 * (k.threads >= 1024 ? 1 : 2);  // workgroups the chip holds (128 VGPRs: 16 waves per CU)
     const int inflight = (resident + t0 + t1 - 1) / (t0 + t1);
-    int lag = plan.fuse_lag > 0 ? plan.fuse_lag : inflight + 1;
-    int ns = plan.fuse_slots > 0 ? plan.fuse_slots : lag + inflight + 1;
+    // measured (profiles/r4/ab_fused_lag_2p*.jsonl): a lag of one in-flight window + 1 leaves second-pass tiles waiting (2^20: 11.3 ms
+    // per pair; lag 3: 14.5), two windows do not (11.0), and a ring beyond 128 MiB falls out of the cache's sweet spot (lag 12 / 24
+    // slots = 192 MiB: 12.2)
+    int lag = plan.fuse_lag > 0 ? plan.fuse_lag : 2 * inflight;
+    int ns = plan.fuse_slots > 0 ? plan.fuse_slots : 2 * lag;
+    while (plan.fuse_slots <= 0 && ns > lag + 1 && (size_t)ns * n * esz > ((size_t)128 << 20)) --ns;  // ring <= 128 MiB
     if (lag < 1) lag = 1;         // a second-pass tile waits for first-pass tiles of an EARLIER step (lower indices) only
     if (ns <= lag) ns = lag + 1;  // a first-pass tile of step s waits for second-pass tiles of step s - ns + lag: an earlier step as well
     if (batch < (size_t)ns) return MI355FFT_ERR_UNSUPPORTED;  // fewer transforms than ring slots: nothing to overlap

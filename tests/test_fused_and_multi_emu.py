@@ -77,14 +77,14 @@ def test_fused_default_ring_and_small_batches(emu_lib):
     assert fus.is_fused()  # the planner's default at 2^20 (measured: profiles/r4)
     ref = _planner(emu_lib).plan_fft_forward(n)
     ref.set_fused(0)
-    for batch in (1, 12):
+    for batch in (1, 18):  # (the default ring at 2^20 has 16 slots)
         x = random_signal(n * batch, np.complex64)
         a, b = x.copy(), x.copy()
         ref.process(a)
         fus.process(b)
         assert np.array_equal(a, b) and fus.fused_status() == 0
     inv = _planner(emu_lib).plan_fft_inverse(n)
-    x = random_signal(n * 11, np.complex64)
+    x = random_signal(n * 17, np.complex64)
     y = x.copy()
     fus.process(y)
     inv.process(y)

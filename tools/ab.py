@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--oop", action="store_true", help="out-of-place calls x -> y (no plan-owned workspace: every arm touches the same two buffers)")
     ap.add_argument("--dist", default="pm1", choices=["pm1", "bench", "zero"], help="input distribution: U[-1,1) | bench.py's U[0,10) * 2^-100 | zeros")
     ap.add_argument("--instances", type=int, default=1, help="plans per arm, each with its own workspace / ring allocations (identical plans run up to 3.6 %% apart depending on which device allocation holds their workspace: the median over instances separates an arm's effect from that lottery)")
+    ap.add_argument("--fwd-only", action="store_true", help="time forward transforms only (2 per iteration) instead of forward + inverse pairs")
     ap.add_argument("--check-all", action="store_true", help="compare every arm's forward output over the WHOLE batch with arm 0's (max abs difference)")
     ap.add_argument("--shift-mib", type=float, default=0, help="allocate this many MiB first (moves the buffers' relative addresses)")
     args = ap.parse_args()
@@ -109,6 +110,9 @@ def main():
                     if args.oop:
                         fwd.process_outofplace_with_scratch(x, y2)
                         inv.process_outofplace_with_scratch(y2, x)
+                    elif args.fwd_only:
+                        fwd.process(x)
+                        fwd.process(x)
                     else:
                         fwd.process(x)
                         inv.process(x)

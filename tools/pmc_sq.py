@@ -51,6 +51,8 @@ def main():
             if c in v:
                 out["frac_" + c] = round(v[c] / wc, 3)
         if v.get("SQ_LDS_IDX_ACTIVE"):
+            # array cycles beyond the conflict-free 2 per access over all array cycles: 1 - 1/k for a k-way conflict; counts write
+            # conflicts that cost no time and the 16-lane groups of ds_read2_b64 (profiles/r4/README.md) -- occupancy, not time
             out["lds_conflict_frac"] = round(v.get("SQ_LDS_BANK_CONFLICT", 0) / v["SQ_LDS_IDX_ACTIVE"], 3)
         print(json.dumps(out))
 
