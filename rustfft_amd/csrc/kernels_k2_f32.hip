@@ -27,7 +27,14 @@ void register_k2_f32(std::vector<KernelEntry>& reg) {
     // 128 KiB writes) moves 4.94 - 5.02 TB/s against 4.41 - 4.47 for the 16-column one; as a later pass (64-byte strided
     // writes) 3.85 against 4.25.
     MI_K2_FIRST(float, 32, 8, true, 2048, 64, 8, 16, 16);
-    MI_K2_LATER(float, 32, 16, true, 2048, 64, 8, 16, 16);
+    // round 4: the LATER pass as two columns per lane (launch.h DevExecPair: 1024 physical threads run 2048 virtual ones, adjacent
+    // columns of the same rows; row loads / stores of 16 bytes): 4.08 -> 3.92 ms per 8 GiB launch at 2^22 (+4 %,
+    // profiles/r4/ab_fused_1024thr_2p22.jsonl variant 54; as a FIRST pass the form loses 9 %: ab_2048_persist.jsonl)
+    MI_K2X_LATER(float, 32, 16, true, 4096, "p2", 2048, 128, 8, 16, 16);
+#if defined(MI355_TUNING)
+    MI_K2_LATER(float, 32, 16, true, 2048, 64, 8, 16, 16);  // tuning 41: one column per lane (the round-3 tile)
+    reg.back().variant = 41;
+#endif
     MI_K2V(40, float, 32, 64, false, 128, 8, 16, 8);       // tuning 40: the kernels before the tables were staged in LDS
     MI_K2V(40, float, 32, 16, true, 1024, 32, 8, 8, 16);
 #if defined(MI355_TUNING)

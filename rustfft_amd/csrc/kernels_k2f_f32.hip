@@ -3,7 +3,7 @@
 // one-pass kernels (kernels_k2_f32.hip) whose tiles it runs.  First macro argument: 1 = the planner's default for that length
 // (interleaved A/B against the two-launch plan, three plan instances per arm, the final lag / ring rule,
 // profiles/r4/ab_fused_final_2p*.jsonl: 2^16 +10.9 %, 2^18 +4.6 %, 2^19 +13.6 %, 2^20 +18.3 % (12.66 -> 10.71 ms per forward + inverse pair);
-// 2^17 -1.5 %, 2^21 -4 %, 2^22 -13 % -- the 2048-row tiles spill in the fused kernel and 2^22's second pass has to run on 8-column tiles).
+// 2^21 -4 %, 2^22 -13 % -- the 2048-row tiles spill in the fused kernel and 2^22's second pass has to run on 8-column tiles).
 #include "launch.h"
 #include "kernel_lists.h"
 namespace mi355 {
@@ -14,7 +14,10 @@ void register_k2f_f32(std::vector<KernelEntry>& reg) {
     using S1024 = Sched<1024, 32, 8, 8, 16>;
     using S2048 = Sched<2048, 64, 8, 16, 16>;
     MI_K2F(1, float, 32, "k2first<256, 16, 16, 16>xF32", 32, false, 0, S256, "k2later<256, 16, 16, 16>xF32", 32, false, 0, S256);              // 2^16
-    MI_K2F(0, float, 32, "k2first<512, 32, 16, 8, 4>xF16t", 16, false, 128, S512F, "k2later<256, 16, 16, 16>xF32", 32, false, 0, S256);       // 2^17
+    // 2^17 in the REVERSED pass order (256-row tile first): two launches 12.32 -> 11.93 ms per pair, fused 10.89 (+13 %); the
+    // standard order fused: 12.36 (profiles/r4/ab_fused_rev_2p17.jsonl).  An AUTO entry that exists for the reversed order only makes
+    // the planner reverse the passes (plan.cpp choose_macro_radices).
+    MI_K2F(1, float, 32, "k2first<256, 16, 16, 16>xF32", 32, false, 0, S256, "k2later<512, 16, 8, 8, 8>xF32t", 32, true, 128, S512L);        // 2^17
     MI_K2F(1, float, 32, "k2first<512, 32, 16, 8, 4>xF16t", 16, false, 128, S512F, "k2later<512, 16, 8, 8, 8>xF32t", 32, true, 128, S512L);   // 2^18
     MI_K2F(1, float, 32, "k2first<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024, "k2later<512, 16, 8, 8, 8>xF32t", 32, true, 128, S512L);   // 2^19
     MI_K2F(1, float, 32, "k2first<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024, "k2later<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024); // 2^20
@@ -23,6 +26,6 @@ void register_k2f_f32(std::vector<KernelEntry>& reg) {
     MI_K2FR(3, float, 32, "k2first<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024, "k2later<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024);
     // 2^22: the one-pass plan runs its second pass on 16-column tiles of 1024 threads; a fused launch has ONE block size, so
     // the second pass runs here on 8-column tiles of 512 threads (two workgroups per CU, like the first pass)
-    MI_K2F(0, float, 32, "k2first<2048, 64, 8, 16, 16>xF8", 8, true, 0, S2048, "k2later<2048, 64, 8, 16, 16>xF16", 8, true, 0, S2048);         // 2^22
+    MI_K2F(0, float, 32, "k2first<2048, 64, 8, 16, 16>xF8", 8, true, 0, S2048, "k2later<2048, 128, 8, 16, 16>xF16p2", 8, true, 0, S2048);         // 2^22
 }
 }  // namespace mi355

@@ -829,10 +829,14 @@ template <class T> KernelEntry make_dyn_rader(int prec) {
 // tuning: other ring-access forms (RINGV 0: plain accesses + release / acquire fences, 2: agent-scope loads, 3: both agent-scope),
 // registered as variant 10 + RINGV (MI355FFT_FUSE_RING)
 #if defined(MI355_TUNING)
+// tuning: any other fused pairing, registered as variant V (MI355FFT_FUSE_RING = 100 + V - 10 selects it)
+#define MI_K2FV(V, T, PREC, NAME0, F0, SP0, ABL0, SCHED0, NAME1, F1, SP1, ABL1, SCHED1) \
+    reg.push_back(make_k2f<T, SCHED0, F0, SP0, ABL0, SCHED1, F1, SP1, ABL1, 1, V>(PREC, "k2fused[" NAME0 " | " NAME1 "]v" #V, NAME0, NAME1))
 #define MI_K2FR(RINGV, T, PREC, NAME0, F0, SP0, ABL0, SCHED0, NAME1, F1, SP1, ABL1, SCHED1) \
     reg.push_back(make_k2f<T, SCHED0, F0, SP0, ABL0, SCHED1, F1, SP1, ABL1, RINGV, 10 + RINGV>(PREC, "k2fused[" NAME0 " | " NAME1 "]r" #RINGV, NAME0, NAME1))
 #else
 #define MI_K2FR(RINGV, T, PREC, NAME0, F0, SP0, ABL0, SCHED0, NAME1, F1, SP1, ABL1, SCHED1) (void)0
+#define MI_K2FV(V, T, PREC, NAME0, F0, SP0, ABL0, SCHED0, NAME1, F1, SP1, ABL1, SCHED1) (void)0
 #endif
 // production instantiations with options (ABL: 64 pair-fused, 128 / 1024 / 2048 sub-pass twiddle tables staged in LDS: all /
 // sub-pass 1 / the last sub-pass); SUF is appended to the kernel name ("t", "t1", "tl")

@@ -12,6 +12,7 @@
 #include <complex>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <mutex>
 #include <sstream>
 
@@ -483,39 +484,75 @@ static bool choose_macro_radices(int prec, size_t n, std::vector<size_t>& out) {
     if (best.empty()) return false;
     out = best;
     if (env_int("MI355FFT_ORDER") == 1) std::reverse(out.begin(), out.end());  // tuning: smallest radix first
+    // a two-pass plan whose REVERSED order (smaller tile first) has a default fused kernel while the standard order has none runs
+    // reversed (2^17 Complex<f32>: measured, kernels_k2f_f32.hip)
+    if (out.size() == 2 && out[0] != out[1] && env_int("MI355FFT_ORDER") == 0) {
+        auto fused_auto = [&](size_t first, size_t later) {
+            const KernelEntry *kf = find_kernel(KIND_K2_FIRST, prec, first), *kl = find_kernel(KIND_K2_LATER, prec, later);
+            if (!kf || !kl) return false;
+            for (auto& e : registry())
+                if (e.kind == KIND_K2_FUSED && e.prec == prec && e.aux == 1 && e.variant == 0 && !strcmp(e.part[0], kf->name) && !strcmp(e.part[1], kl->name)) return true;
+            return false;
+        };
+        if (!fused_auto(out[0], out[1]) && fused_auto(out[1], out[0])) std::swap(out[0], out[1]);
+    }
     return true;
 }
 
 // radices for a composite length that is not a power of two: tile heights with a compiled general pass kernel
-// (k2g_body), fewest passes, then the most balanced split
+// (k2g_body), fewest passes, then the split that wastes the fewest columns, then the most balanced one.
+// Column waste: pass p runs ceil(M_p / F_p) tiles of F_p columns over M_p = n / R_p columns, and the short tile heights are WIDE
+// (up to 128 columns, so that a workgroup has enough threads): the balanced split of a length just above 4096 -- 4225 = 65 x 65 --
+// is one 128-column tile per transform with 63 columns masked, 1.97x the work and traffic, where 169 x 25 wastes 1.40x.  185 of the
+// 13-smooth lengths below 20000 lose more than 12 % that way (profiles/r4/general_split_waste.json); the cost below is the mean
+// padded-over-real column ratio of the passes, compared in steps of 10 % (smaller differences: the balanced split).
 static bool choose_general_radices(int prec, size_t n, std::vector<size_t>& out) {
     std::vector<size_t> avail;
+    std::vector<int> width;
     for (auto& e : registry())
         if ((e.kind == KIND_K2G_FIRST || (e.kind == KIND_K2R_FIRST && env_int("MI355FFT_NO_K2R") == 0)) && e.prec == prec) avail.push_back(e.n);
     std::sort(avail.begin(), avail.end(), std::greater<size_t>());
-    std::vector<size_t> best, cur;
-    size_t best_max = 0;
-    for (int P = 2; P <= 4 && best.empty(); ++P) {
-        struct Rec {
-            static void go(const std::vector<size_t>& av, size_t start, size_t rem, int left, std::vector<size_t>& cur,
-                           std::vector<size_t>& best, size_t& best_max) {
-                if (left == 0) {
-                    if (rem == 1 && (best.empty() || cur.front() < best_max)) {
-                        best = cur;
-                        best_max = cur.front();
-                    }
-                    return;
-                }
-                for (size_t i = start; i < av.size(); ++i) {
-                    if (rem % av[i]) continue;
-                    cur.push_back(av[i]);
-                    go(av, i, rem / av[i], left - 1, cur, best, best_max);
-                    cur.pop_back();
-                }
-            }
-        };
-        Rec::go(avail, 0, n, P, cur, best, best_max);
+    for (size_t r : avail) {
+        const KernelEntry* k = find_kernel(KIND_K2G_FIRST, prec, r);
+        if (!k) k = find_kernel(KIND_K2R_FIRST, prec, r);
+        width.push_back(k ? k->f : 1);
     }
+    std::vector<size_t> best, cur;
+    std::vector<size_t> idx;
+    long best_cost = 0;
+#if defined(MI355_SPLIT_BALANCED)  // A/B builds: the round-3 rule (most balanced split)
+    const bool waste_aware = false;
+#else
+    // Complex<f32> only: measured on 48 / 10 changed lengths (profiles/r4/ab_split_waste_*.jsonl) f32 gains wherever the waste drops
+    // by 0.15 or more (+12 ... +41 %; median of all changed lengths +3.9 %), f64 -- narrower tiles, less to gain, and the
+    // alternative splits bring radix-13 tiles -- loses on 4 of 10
+    const bool waste_aware = prec == 32 && env_int("MI355FFT_SPLIT_BALANCED") == 0;
+#endif
+    std::function<void(size_t, size_t, int)> go = [&](size_t start, size_t rem, int left) {
+        if (left == 0) {
+            if (rem != 1) return;
+            double c = 0;
+            for (size_t p = 0; p < cur.size(); ++p) {
+                const size_t M = n / cur[p], f = (size_t)width[idx[p]];
+                c += (double)(((M + f - 1) / f) * f) / (double)M;
+            }
+            const long cost = waste_aware ? std::lround(c / (double)cur.size() * 10.0) : 0;  // 10 % steps
+            if (best.empty() || cost < best_cost || (cost == best_cost && cur.front() < best.front())) {
+                best = cur;
+                best_cost = cost;
+            }
+            return;
+        }
+        for (size_t i = start; i < avail.size(); ++i) {
+            if (rem % avail[i]) continue;
+            cur.push_back(avail[i]);
+            idx.push_back(i);
+            go(i, rem / avail[i], left - 1);
+            cur.pop_back();
+            idx.pop_back();
+        }
+    };
+    for (int P = 2; P <= 4 && best.empty(); ++P) go(0, n, P);
     if (best.empty()) return false;
     out = best;
     return true;

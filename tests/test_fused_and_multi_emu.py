@@ -220,3 +220,20 @@ def test_multi_device_resident_shards_and_edges(emu_lib, monkeypatch):
     assert np.array_equal(np.concatenate(outs), want) and np.array_equal(np.concatenate(ins), x)
     with pytest.raises(ValueError):
         multi.process([_Dev(shards[1]), _Dev(shards[0])])  # the shards must hold their own rows
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_general_split_prefers_full_tiles(emu_lib, oracle, dtype):
+    """Round 4 planner rule (plan.cpp choose_general_radices): among the splits with the fewest passes, the one that wastes the
+    fewest tile columns, not the most balanced one -- 4225 = 65 x 65 would be ONE 128-column tile per transform with 63 columns
+    masked (Complex<f32> tile widths).  A sample of the lengths whose split changes, all API modes against the oracle."""
+    from helpers import check_fft_algorithm
+
+    planner = _planner(emu_lib, dtype)
+    for n in (4225, 4290, 5005, 5265, 6435, 8085, 9009, 12005):
+        for d in (0, 1):
+            fft = planner.plan_fft(n, d)
+            assert fft.describe().startswith("k2gfirst<") and "->" in fft.describe(), fft.describe()
+            check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=2)
+    if dtype == np.complex64:
+        assert planner.plan_fft_forward(4225).describe().startswith("k2gfirst<169,"), planner.plan_fft_forward(4225).describe()

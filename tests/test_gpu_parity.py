@@ -541,7 +541,7 @@ def test_random_lengths_vs_float64(planners, dtype):
         batch = int(rng.integers(1, max(2, min(40, 400000 // n))))
         d = int(rng.integers(0, 2))
         fft = planner.plan_fft(n, d)
-        seen.add(fft.describe().split("<")[0].split("(")[0])
+        seen.add(fft.describe().replace("fused{", "").split("<")[0].split("(")[0])  # (a fused two-pass plan is still the k2 kernel family)
         x = zero_mean_signal(n * batch, dtype, seed=n)
         y = x.copy()
         fft.process(y)
