@@ -574,9 +574,10 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBS, "traffic": None,
                                "kernel": "k2fused[" + " | ".join(names) + "]", "ms": fused_ms, "algorithmic_bytes_per_launch": alg_bytes,
                                "launches_per_transform": 1, "fused_error_word": status,
-                               "what": "ONE launch does the whole transform: algorithmic bytes = one read + one write of the batch (SURVEY section 8(d)), "
-                                       "which is also all the HBM traffic the launch causes (`traffic`); the intermediate crosses the CU <-> memory fabric "
-                                       "twice more, out of and into the Infinity Cache",
+                               "what": "ONE launch does the whole transform: algorithmic bytes = one read + one write of the batch (SURVEY section 8(d)); the "
+                                       "intermediate crosses the CU <-> memory fabric twice more, out of and into a ring that stays in the Infinity Cache.  "
+                                       "`traffic` (FETCH_SIZE / WRITE_SIZE) counts the L2 <-> fabric requests, Infinity-Cache hits included (MI355X_MICROARCH.md, HBM "
+                                       "section), i.e. all four crossings: compare it with 2 x algorithmic_bytes_per_launch",
                                "per_pass_equivalent": {"GBps": 2 * gbps, "frac": 2 * gbps / HBM_PEAK_GBS,
                                                        "what": "both passes' algorithmic bytes over the launch: the figure comparable with the per-kernel "
                                                                "fractions of a two-launch plan (earlier rounds' `frac`)"},

@@ -212,6 +212,16 @@ int process_host_impl(const mi355fft_plan* cplan, const void* in, size_t n_in, v
             if (e) backend::event_destroy(e);
         if (rc_main != MI355FFT_OK) return rc_main;
         if (rc_dl != MI355FFT_OK) return set_err(rc_dl, err_dl);
+        // a fused two-pass launch bounds its cross-workgroup waits and raises an error word instead of hanging: this path has
+        // just synchronised the stream, so the word is final -- results of a launch that gave up are not handed to the caller as good
+        {
+            StreamSlot& slot = plan.slot_for(cx.stream_a);
+            std::lock_guard<std::mutex> g(slot.launch_mutex);
+            unsigned word = 0;
+            if (slot.pipe.ctrl && (backend::d2h(&word, (const char*)slot.pipe.ctrl + sizeof(unsigned), sizeof(unsigned), cx.stream_a) || backend::sync(cx.stream_a)))
+                return hip_err(MI355FFT_ERR_HIP);
+            if (word) return set_err(MI355FFT_ERR_HIP, "a fused two-pass launch gave up waiting for a dependency (mi355fft_plan_fused_status)");
+        }
     }
     // a trailing partial chunk is reported after the complete chunks were transformed (array_utils.rs:164-176)
     if (rem != 0) return validation_error(len, n_in, n_out, false);

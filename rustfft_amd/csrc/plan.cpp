@@ -1449,6 +1449,7 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
 // (writes chunk c of `out`) only, so all three API modes are the same code and `in` is never clobbered.  The last pass runs
 // on the caller's stream and depends on everything else, so the call stays asynchronous and stream-ordered for the caller
 // (and capturable: the side streams fork from and join the caller's stream through events).
+#if defined(MI355_TUNING) || defined(MI355_EMU)  // measured slower than one launch per pass AND than the fused launch (profiles/r4/ab_pipe_*): kept as the experiment it was
 template <class T> static int execute_pipelined(Plan& plan, const void* in, void* out, size_t batch, void* stream) {
     const size_t esz = 2 * sizeof(T), n = plan.len, P = plan.passes.size();
     const size_t slot_target = plan.pipe_slot_bytes ? plan.pipe_slot_bytes : ((size_t)64 << 20);
@@ -1504,6 +1505,8 @@ template <class T> static int execute_pipelined(Plan& plan, const void* in, void
     return MI355FFT_OK;
 }
 
+
+#endif
 
 // ---- fused two-pass launch ---------------------------------------------------------------------------------------------------
 // Both passes of a two-pass power-of-two plan in ONE launch (launch.h k2f_kernel): pass 2 of transform g - lag runs beside
@@ -1660,7 +1663,9 @@ template <class T> static int execute_t(Plan& plan, const void* in, void* out, s
         const int rcf = execute_fused<T>(plan, in, out, batch, stream);
         if (rcf != MI355FFT_ERR_UNSUPPORTED) return rcf;  // a batch too small to pipeline runs as two launches
     }
+#if defined(MI355_TUNING) || defined(MI355_EMU)
     if (plan.pipe_mode > 0 && tr == nullptr && plan.kind == PLAN_MACRO) return execute_pipelined<T>(plan, in, out, batch, stream);
+#endif
 
     // Buffer rotation.  Every pass but the last is out-of-place; the last one may run in place.
     //   in-place : buf -> ws -> buf -> ws ... -> buf

@@ -230,7 +230,7 @@ def test_general_split_prefers_full_tiles(emu_lib, oracle, dtype):
     from helpers import check_fft_algorithm
 
     planner = _planner(emu_lib, dtype)
-    for n in (4225, 4290, 5005, 5265, 6435, 8085, 9009, 12005):
+    for n in (4225, 4290, 5005, 5265, 6435, 8085, 9009, 15015):
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
             assert fft.describe().startswith("k2gfirst<") and "->" in fft.describe(), fft.describe()

@@ -1084,3 +1084,20 @@ def test_bench_two_ranks_on_one_gpu():
     assert "FAILED" not in line["check"] and line["check"]["roundtrip_rel_l2"] < 5e-6
     assert line["config5"]["parseval_max_rel_err_over_ranks"] < 1e-4
     assert line["edges"]["scatter_s"] > 0
+
+
+def test_bench_via_cabi_two_shards_on_one_gpu():
+    """The multi-GPU path behind the boundary, end to end: `bench.py --via-cabi --gpus 2 --one-device` -- ONE process, one
+    mi355fft_multi_plan over the device list [0, 0], device-resident shards, mi355fft_multi_process_inplace_dev +
+    mi355fft_multi_synchronize around the timed region; the line must carry a passing round-trip check."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--via-cabi", "--gpus", "2", "--one-device", "--steps", "3", "--warmup", "1", "--batch", "128"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    assert "FAILED" not in line["check"] and line["config"]["finite"]
