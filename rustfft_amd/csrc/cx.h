@@ -142,11 +142,14 @@ template <class T> MI_HD void st_agent(cx<T>* p, cx<T> v) {
         __builtin_memcpy(&u, &v, 8);
         __hip_atomic_store((unsigned long long*)p, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-        unsigned long long a, b;
-        __builtin_memcpy(&a, &v.re, 8);
-        __builtin_memcpy(&b, &v.im, 8);
-        __hip_atomic_store((unsigned long long*)p, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store((unsigned long long*)p + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ONE 16-byte write-through store (the atomic builtins stop at 8 bytes: two of them per element cost Complex<f64> 16 - 26 %,
+        // profiles/r4/ab_fused_f64_2p*.jsonl)
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const v2d t = {v.re, v.im};
+        // (s_nop 1 inside the statement: the compiler pads nothing in an asm string, and its next instruction may otherwise overwrite the
+        // data registers of a 16-byte store before the store has read them -- cdna_hip_programming.md section 5.7; found the hard way:
+        // without it 2^17, 2^18 and 2^20 came out wrong on the device while every emulator test passed)
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(t) : "memory");
     }
 #else
     *p = v;

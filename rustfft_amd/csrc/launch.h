@@ -201,7 +201,7 @@ template <class T> __device__ __forceinline__ void k2f_wait(unsigned* ctr, unsig
 template <class T, class S0, int F0, bool SPLIT0, int ABL0, class S1, int F1, bool SPLIT1, int ABL1, int RINGV>
 __global__ __launch_bounds__((k2_threads<S0, F0, ABL0>()), (k2_threads<S0, F0, ABL0>() >= 512 ? 4 : 2)) void k2f_kernel(K2FusedParams<T> fp) {
     static_assert(k2_threads<S0, F0, ABL0>() == k2_threads<S1, F1, ABL1>(), "one block size for both passes");
-    static_assert(!(ABL0 & 4096) && !(ABL1 & 4096), "plain executors");
+    static_assert(!(ABL0 & 4096), "the first pass runs on a plain executor (its ring stores are per element)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ unsigned s_ticket;
     long long w = (long long)blockIdx.x;
@@ -242,7 +242,8 @@ __global__ __launch_bounds__((k2_threads<S0, F0, ABL0>()), (k2_threads<S0, F0, A
             }
             __syncthreads();
         }
-        DevExec<T, regs_needed<S1, SPLIT1>()> ex;
+        // (ABL bit 4096: the second pass as two columns per lane -- 16-byte ring loads and 16-byte stores, launch.h DevExecPair)
+        typename std::conditional<(ABL1 & 4096) != 0, DevExecPair<T, regs_needed<S1, SPLIT1>()>, DevExec<T, regs_needed<S1, SPLIT1>()>>::type ex;
         k2_tile<T, S1, F1, false, SPLIT1, ABL1, (RINGV & 2)>(ex, fp.pass[1], (const cx<T>*)ring, fp.pass[1].out + it.g * n, it.tile, smem);
         if (sync) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

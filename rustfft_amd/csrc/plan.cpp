@@ -34,6 +34,7 @@ void ensure_registry() {
         register_k2_f32(r);
         register_k2_f64(r);
         register_k2f_f32(r);
+        register_k2f_f64(r);
         register_np2_f32(r);
 #if defined(MI355_MINIMAL)
         register_bs57_f32(r);

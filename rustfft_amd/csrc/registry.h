@@ -50,6 +50,7 @@ void register_k1_f64(std::vector<KernelEntry>&);
 void register_k2_f32(std::vector<KernelEntry>&);
 void register_k2_f64(std::vector<KernelEntry>&);
 void register_k2f_f32(std::vector<KernelEntry>&);  // fused two-pass kernels (kernels_k2f_f32.hip)
+void register_k2f_f64(std::vector<KernelEntry>&);
 void register_np2_f32(std::vector<KernelEntry>&);  // non-power-of-two: mixed radix, Rader, Bluestein
 void register_np2_f64(std::vector<KernelEntry>&);
 void register_bs57_f32(std::vector<KernelEntry>&);  // Bluestein bodies over 5 * 2^k and 7 * 2^k
