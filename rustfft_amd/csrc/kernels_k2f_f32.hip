@@ -2,7 +2,8 @@
 // intermediate in a cache-resident ring.  One entry per two-pass plan 2^16 .. 2^22, Complex<float>; each names the two
 // one-pass kernels (kernels_k2_f32.hip) whose tiles it runs.  First macro argument: 1 = the planner's default for that length
 // (interleaved A/B against the two-launch plan, three plan instances per arm, the final lag / ring rule,
-// profiles/r4/ab_fused_final_2p*.jsonl: 2^16 +10.9 %, 2^18 +4.6 %, 2^19 +13.6 %, 2^20 +18.3 % (12.66 -> 10.71 ms per forward + inverse pair);
+// profiles/r4/ab_fused_final_2p*.jsonl: 2^16 +10.9 %, 2^19 +13.6 %, 2^20 +18.3 % (12.66 -> 10.71 ms per forward + inverse pair); steady-state
+// forward-only launches at 4 GiB, profiles/r4/fused_warmup_2p*.jsonl: 2^16 +8 %, 2^17 +11 %, 2^19 +14 %, 2^20 +11 %, 2^18 +-0 -- 2^18 stays off;
 // 2^21 -4 %, 2^22 -13 % -- the 2048-row tiles spill in the fused kernel and 2^22's second pass has to run on 8-column tiles).
 #include "launch.h"
 #include "kernel_lists.h"
@@ -18,7 +19,7 @@ void register_k2f_f32(std::vector<KernelEntry>& reg) {
     // standard order fused: 12.36 (profiles/r4/ab_fused_rev_2p17.jsonl).  An AUTO entry that exists for the reversed order only makes
     // the planner reverse the passes (plan.cpp choose_macro_radices).
     MI_K2F(1, float, 32, "k2first<256, 16, 16, 16>xF32", 32, false, 0, S256, "k2later<512, 16, 8, 8, 8>xF32t", 32, true, 128, S512L);        // 2^17
-    MI_K2F(1, float, 32, "k2first<512, 32, 16, 8, 4>xF16t", 16, false, 128, S512F, "k2later<512, 16, 8, 8, 8>xF32t", 32, true, 128, S512L);   // 2^18
+    MI_K2F(0, float, 32, "k2first<512, 32, 16, 8, 4>xF16t", 16, false, 128, S512F, "k2later<512, 16, 8, 8, 8>xF32t", 32, true, 128, S512L);   // 2^18
     MI_K2F(1, float, 32, "k2first<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024, "k2later<512, 16, 8, 8, 8>xF32t", 32, true, 128, S512L);   // 2^19
     MI_K2F(1, float, 32, "k2first<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024, "k2later<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024); // 2^20
     MI_K2F(0, float, 32, "k2first<2048, 64, 8, 16, 16>xF8", 8, true, 0, S2048, "k2later<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024);     // 2^21

@@ -53,7 +53,7 @@ def main():
         if args.check:
             want = np.fft.fft(x0.astype(np.complex128))
             err = float(np.linalg.norm(x[:n].cpu().numpy() - want) / np.linalg.norm(want))
-        for _ in range(2):  # (the first launches into freshly allocated buffers run up to 10 % slow: measured on the fused plans, profiles/r4/README.md)
+        for _ in range(8 if fft.is_fused() else 2):  # (a fused plan reaches its steady rate after ~10 launches of a fresh process, ~5 of a new plan: profiles/r4/fused_warmup_*.jsonl)
             torch.view_as_real(x).uniform_(-1.0, 1.0)
             fft.process(x)
         torch.view_as_real(x).uniform_(-1.0, 1.0)
