@@ -179,20 +179,22 @@ template <class T, bool FIRST, int ABL = 0, int F_ = 0, int RING = 0> struct K2S
 // The tile of a power-of-two column-tile pass: transform g's rows at `in` / `out`, columns [tile F, (tile + 1) F).  k2_body maps a
 // workgroup index to (g, tile) for the one-pass-per-launch kernels, k2f_body (below) for the fused two-pass kernel.
 // RING (fused kernel): bit 0 = `out` is the ring: agent-scope stores; bit 1 = `in` is the ring: agent-scope loads (cx.h)
+// `tile` places the columns the tile READS, `tile_out` the ones it WRITES (and its inter-pass factors): equal except for the units of a
+// fused three-pass launch (kernels_params.h), whose ring holds a compact copy of a unit's columns.
 template <class T, class S, int F, bool FIRST, bool SPLIT, int ABL = 0, int RING = 0, class X>
-MI_HD void k2_tile(X& ex, const K2Params<T>& p, const cx<T>* in, cx<T>* out, unsigned tile, void* lds) {
+MI_HD void k2_tile(X& ex, const K2Params<T>& p, const cx<T>* in, cx<T>* out, unsigned tile, unsigned tile_out, void* lds) {
     constexpr int R = S::N;
-    const unsigned b0 = tile * (unsigned)F;
+    const unsigned b0 = tile * (unsigned)F, bo = tile_out * (unsigned)F;
     const unsigned M = (unsigned)p.m, s32 = (unsigned)p.s;
     const T sgn_out = p.sgn_out;
     // a tile never straddles a multiple of S (F | S whenever S > 1), so B div S is tile-uniform
-    const unsigned bdiv = FIRST ? 0u : (b0 >> p.s_shift);
-    const unsigned bmod0 = FIRST ? 0u : (b0 & (s32 - 1u));
+    const unsigned bdiv = FIRST ? 0u : (bo >> p.s_shift);
+    const unsigned bmod0 = FIRST ? 0u : (bo & (s32 - 1u));
     const unsigned obase = bdiv * s32 * (unsigned)R + bmod0;
     K2Src<T, FIRST, ABL, F, RING> src{in, M, b0, bmod0, p.sgn_in, p.tlo, p.thi, p.hshift, p.lmask};
     auto dst = [=](int f, int k, cx<T> x) {
         x.im *= sgn_out;
-        cx<T>* o = FIRST ? out + ((b0 + (unsigned)f) * (unsigned)R + (unsigned)k) : out + (obase + (unsigned)f + (unsigned)k * s32);
+        cx<T>* o = FIRST ? out + ((bo + (unsigned)f) * (unsigned)R + (unsigned)k) : out + (obase + (unsigned)f + (unsigned)k * s32);
         if constexpr ((RING & 1) != 0)
             st_agent(o, x);
         else if constexpr ((ABL & 32) != 0)
@@ -276,15 +278,16 @@ MI_HD void k2_body(X& ex, const K2Params<T>& p, long long block, void* lds) {
     // scalar instructions in front of the first load of the workgroup)
     const long long g = block >> p.tiles_shift;
     const unsigned tile = (unsigned)(block & ((1LL << p.tiles_shift) - 1));
-    k2_tile<T, S, F, FIRST, SPLIT, ABL, 0>(ex, p, p.in + g * p.n, p.out + g * p.n, tile, lds);
+    k2_tile<T, S, F, FIRST, SPLIT, ABL, 0>(ex, p, p.in + g * p.n, p.out + g * p.n, tile, tile, lds);
 }
 // ---- fused two-pass kernel: work-item decoding (shared by the gfx950 kernel and the host emulator) ------------------------
 struct K2FItem {
     int pass;        // 0 / 1; -1: nothing to do (index past the end)
     long long g;     // transform
-    unsigned tile;   // tile within the transform, XCD-aware order applied
-    unsigned slot;   // ring slot g % ns
-    unsigned use;    // g / ns: how many times the slot has been used before
+    unsigned tile;   // tile within the transform, XCD-aware order applied: where it reads ...
+    unsigned tile_out;  // ... and where it writes (differs for the units of a three-pass plan, kernels_params.h)
+    unsigned slot;   // ring slot: step % ns
+    unsigned use;    // step / ns: how many times the slot has been used before
 };
 // Steps of t0 + t1 items.  Within a step the items go in groups of eight per pass -- items [16 q, 16 q + 8) are first-pass tiles,
 // [16 q + 8, 16 q + 16) second-pass tiles (when t0 == t1 and both are multiples of 8; otherwise first-pass tiles, then
@@ -303,8 +306,8 @@ template <class T> MI_HD K2FItem k2f_decode(const K2FusedParams<T>& fp, long lon
         it.pass = r < t0 ? 0 : 1;
         i = it.pass ? r - t0 : r;
     }
-    it.g = it.pass ? (long long)s - fp.lag : (long long)s;
-    if (it.g < 0 || it.g >= fp.batch) {
+    const long long st = it.pass ? (long long)s - fp.lag : (long long)s;  // the step (transform x unit) this item belongs to
+    if (st < 0 || st >= fp.batch) {
         it.pass = -1;
         return it;
     }
@@ -313,9 +316,18 @@ template <class T> MI_HD K2FItem k2f_decode(const K2FusedParams<T>& fp, long lon
         const unsigned rr = i & ((8u << p.xq) - 1u), x = rr & 7u, j = rr >> 3;
         i += (((j >> p.xp) << (p.xp + 3)) | (x << p.xp) | (j & ((1u << p.xp) - 1u))) - rr;
     }
-    it.tile = i;
-    it.use = MI_UNIFORM((unsigned)it.g / (unsigned)fp.ns);
-    it.slot = (unsigned)it.g - it.use * (unsigned)fp.ns;
+    const unsigned U = (unsigned)fp.units;
+    unsigned u = 0;
+    it.g = st;
+    if (U > 1) {
+        const unsigned g32 = MI_UNIFORM((unsigned)st / U);
+        it.g = (long long)g32;
+        u = (unsigned)st - g32 * U;
+    }
+    it.tile = it.pass ? i : u + i * U;
+    it.tile_out = it.pass ? u * t1 + i : i;
+    it.use = MI_UNIFORM((unsigned)st / (unsigned)fp.ns);
+    it.slot = (unsigned)st - it.use * (unsigned)fp.ns;
     return it;
 }
 // LDS bytes of a column-tile workgroup: the exchange buffer + the staged twiddle tables

@@ -20,6 +20,10 @@ void register_k2f_f32(std::vector<KernelEntry>& reg) {
     // the planner reverse the passes (plan.cpp choose_macro_radices).
     MI_K2F(1, float, 32, "k2first<256, 16, 16, 16>xF32", 32, false, 0, S256, "k2later<512, 16, 8, 8, 8>xF32t", 32, true, 128, S512L);        // 2^17
     MI_K2F(0, float, 32, "k2first<512, 32, 16, 8, 4>xF16t", 16, false, 128, S512F, "k2later<512, 16, 8, 8, 8>xF32t", 32, true, 128, S512L);   // 2^18
+    // 2^18 as 256 x 1024: forward-only, 4 GiB, three plan instances per arm (profiles/r4/ab_fused_2p18_splits.jsonl): 512 x 512 two launches
+    // 5.92 ms, fused 5.81; 1024 x 256 6.18 / 5.69; 256 x 1024 6.33 / 5.40 (+9.6 % over the balanced two-launch plan).  The planner takes
+    // the split that has a default fused kernel (plan.cpp choose_macro_radices).
+    MI_K2F(1, float, 32, "k2first<256, 16, 16, 16>xF32", 32, false, 0, S256, "k2later<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024);
     MI_K2F(1, float, 32, "k2first<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024, "k2later<512, 16, 8, 8, 8>xF32t", 32, true, 128, S512L);   // 2^19
     MI_K2F(1, float, 32, "k2first<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024, "k2later<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024); // 2^20
     MI_K2F(0, float, 32, "k2first<2048, 64, 8, 16, 16>xF8", 8, true, 0, S2048, "k2later<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024);     // 2^21

@@ -59,10 +59,18 @@ template <class T> struct K2FusedParams {
     unsigned* ctrl;
     int tiles[2];          // t0, t1: tiles per transform of the two passes
     int lag, ns;
-    long long batch;
+    long long batch;       // STEPS of the launch: transforms x units
+    int units;             // U >= 1: closed groups of tiles per transform (1 for a two-pass plan; three-pass plans: see below)
+    long long slot_elems;  // elements of a ring slot (n / U)
     int mode;              // bit 0: dependency flags + fences (0 = timing probe only, results undefined); bit 1: work items by ticket
     int spin_limit;        // polls before a wait gives up and sets the error word
 };
+// Passes 0 and 1 of a THREE-pass plan N = R0 R1 R2 through the same kernel.  The tiles of the two passes close into U = R2 / F0 UNITS per
+// transform: unit u is the R1 first-pass tiles with columns [u F0 + j R2, u F0 + j R2 + F0) (j < R1) and the F0 R0 / F1 second-pass tiles
+// with B div R0 in [u F0, (u + 1) F0) -- the former write exactly what the latter read, F0 R0 R1 elements.  A step of the launch is a unit,
+// a ring slot holds one unit in COMPACT form (first-pass tile j writes at column base j F0; the second pass reads it as an
+// (R1) x (F0 R0) matrix: pass[1].m = F0 R0), and the tile index splits in two: where a tile reads (`tile`) and where it writes
+// (`tile_out`) -- pass 0: u + j U / j, pass 1: i / u t1 + i.  U = 1 is the two-pass plan (both indices equal).
 constexpr int k2f_ctrl_words(int ns) { return 32 + 64 * ns + 64; }
 // workgroups of a fused launch: batch + lag steps of t0 + t1 items (the items of a step that have no transform do nothing)
 constexpr long long k2f_grid(long long batch, int t0, int t1, int lag) { return (batch + lag) * (long long)(t0 + t1); }

@@ -215,7 +215,7 @@ __global__ __launch_bounds__((k2_threads<S0, F0, ABL0>()), (k2_threads<S0, F0, A
     unsigned* written = fp.ctrl + 32 + 64 * it.slot;
     unsigned* rd = fp.ctrl + 64 + 64 * it.slot;
     const long long n = fp.pass[0].n;
-    cx<T>* ring = fp.pass[0].out + (long long)it.slot * n;
+    cx<T>* ring = fp.pass[0].out + (long long)it.slot * fp.slot_elems;
     const bool sync = (fp.mode & 1) != 0;
     const bool release = sync && !(RINGV & 1) && !(fp.mode & 4), acquire = sync && !(RINGV & 2) && !(fp.mode & 8);  // mode bits 2, 3: probes
     if (it.pass == 0) {
@@ -224,7 +224,7 @@ __global__ __launch_bounds__((k2_threads<S0, F0, ABL0>()), (k2_threads<S0, F0, A
             __syncthreads();
         }
         DevExec<T, regs_needed<S0, SPLIT0>()> ex;
-        k2_tile<T, S0, F0, true, SPLIT0, ABL0, (RINGV & 1)>(ex, fp.pass[0], fp.pass[0].in + it.g * n, ring, it.tile, smem);
+        k2_tile<T, S0, F0, true, SPLIT0, ABL0, (RINGV & 1)>(ex, fp.pass[0], fp.pass[0].in + it.g * n, ring, it.tile, it.tile_out, smem);
         if (sync) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -244,7 +244,7 @@ __global__ __launch_bounds__((k2_threads<S0, F0, ABL0>()), (k2_threads<S0, F0, A
         }
         // (ABL bit 4096: the second pass as two columns per lane -- 16-byte ring loads and 16-byte stores, launch.h DevExecPair)
         typename std::conditional<(ABL1 & 4096) != 0, DevExecPair<T, regs_needed<S1, SPLIT1>()>, DevExec<T, regs_needed<S1, SPLIT1>()>>::type ex;
-        k2_tile<T, S1, F1, false, SPLIT1, ABL1, (RINGV & 2)>(ex, fp.pass[1], (const cx<T>*)ring, fp.pass[1].out + it.g * n, it.tile, smem);
+        k2_tile<T, S1, F1, false, SPLIT1, ABL1, (RINGV & 2)>(ex, fp.pass[1], (const cx<T>*)ring, fp.pass[1].out + it.g * n, it.tile, it.tile_out, smem);
         if (sync) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -611,16 +611,16 @@ KernelEntry make_k2f(int prec, const char* name, const char* part0, const char* 
             if (it.pass < 0) continue;
             unsigned* written = fp.ctrl + 32 + 64 * it.slot;
             unsigned* rd = fp.ctrl + 64 + 64 * it.slot;
-            cx<T>* ring = fp.pass[0].out + (long long)it.slot * n;
+            cx<T>* ring = fp.pass[0].out + (long long)it.slot * fp.slot_elems;
             if (it.pass == 0) {
                 if (it.use > 0 && *rd < it.use * (unsigned)fp.tiles[1]) fp.ctrl[1] |= 2u;
                 HostExec<T, regs_needed<S0, SPLIT0>()> ex(F0 * S0::TPF);
-                k2_tile<T, S0, F0, true, SPLIT0, ABL0>(ex, fp.pass[0], fp.pass[0].in + it.g * n, ring, it.tile, lds.data());
+                k2_tile<T, S0, F0, true, SPLIT0, ABL0>(ex, fp.pass[0], fp.pass[0].in + it.g * n, ring, it.tile, it.tile_out, lds.data());
                 *written += 1;
             } else {
                 if (*written < (it.use + 1u) * (unsigned)fp.tiles[0]) fp.ctrl[1] |= 2u;
                 HostExec<T, regs_needed<S1, SPLIT1>()> ex(F1 * S1::TPF);
-                k2_tile<T, S1, F1, false, SPLIT1, ABL1>(ex, fp.pass[1], (const cx<T>*)ring, fp.pass[1].out + it.g * n, it.tile, lds.data());
+                k2_tile<T, S1, F1, false, SPLIT1, ABL1>(ex, fp.pass[1], (const cx<T>*)ring, fp.pass[1].out + it.g * n, it.tile, it.tile_out, lds.data());
                 *rd += 1;
             }
         }

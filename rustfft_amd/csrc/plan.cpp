@@ -484,10 +484,20 @@ static bool choose_macro_radices(int prec, size_t n, std::vector<size_t>& out) {
     }
     if (best.empty()) return false;
     out = best;
+    if (const int r0 = env_int("MI355FFT_R0"))  // tuning: a two-pass plan with this first tile height
+        if (n % (size_t)r0 == 0 && find_kernel(KIND_K2_FIRST, prec, (size_t)r0) && find_kernel(KIND_K2_LATER, prec, n / (size_t)r0)) {
+            out = {(size_t)r0, n / (size_t)r0};
+            return true;
+        }
     if (env_int("MI355FFT_ORDER") == 1) std::reverse(out.begin(), out.end());  // tuning: smallest radix first
-    // a two-pass plan whose REVERSED order (smaller tile first) has a default fused kernel while the standard order has none runs
-    // reversed (2^17 Complex<f32>: measured, kernels_k2f_f32.hip)
-    if (out.size() == 2 && out[0] != out[1] && env_int("MI355FFT_ORDER") == 0) {
+    // a two-pass plan whose balanced split has no default fused kernel while ANOTHER split (or pass order) of the same length has one
+    // takes that one (Complex<f32>: 2^17 as 256 x 512, 2^18 as 256 x 1024 -- measured, kernels_k2f_f32.hip)
+    if (out.size() == 2 && env_int("MI355FFT_ORDER") == 0) {
+        auto named = [&](int kind, const char* name) -> const KernelEntry* {
+            for (auto& e : registry())
+                if (e.kind == kind && e.prec == prec && e.variant == 0 && !strcmp(e.name, name)) return &e;
+            return nullptr;
+        };
         auto fused_auto = [&](size_t first, size_t later) {
             const KernelEntry *kf = find_kernel(KIND_K2_FIRST, prec, first), *kl = find_kernel(KIND_K2_LATER, prec, later);
             if (!kf || !kl) return false;
@@ -495,7 +505,15 @@ static bool choose_macro_radices(int prec, size_t n, std::vector<size_t>& out) {
                 if (e.kind == KIND_K2_FUSED && e.prec == prec && e.aux == 1 && e.variant == 0 && !strcmp(e.part[0], kf->name) && !strcmp(e.part[1], kl->name)) return true;
             return false;
         };
-        if (!fused_auto(out[0], out[1]) && fused_auto(out[1], out[0])) std::swap(out[0], out[1]);
+        if (!fused_auto(out[0], out[1]))
+            for (auto& e : registry()) {
+                if (e.kind != KIND_K2_FUSED || e.prec != prec || e.aux != 1 || e.variant != 0 || (size_t)e.n != n) continue;
+                const KernelEntry *kf = named(KIND_K2_FIRST, e.part[0]), *kl = named(KIND_K2_LATER, e.part[1]);
+                if (kf && kl && (size_t)kf->n * (size_t)kl->n == n && fused_auto((size_t)kf->n, (size_t)kl->n)) {
+                    out = {(size_t)kf->n, (size_t)kl->n};
+                    break;
+                }
+            }
     }
     return true;
 }
@@ -1184,13 +1202,19 @@ int build_plan(Plan& plan) {
     const int rc = plan.prec == 32 ? build_plan_t<float>(plan) : build_plan_t<double>(plan);
     if (rc) return rc;
     // a fused two-pass kernel for exactly this pair of column-tile passes, if one is compiled
-    if (plan.kind == PLAN_MACRO && plan.passes.size() == 2 && plan.passes[0].k->kind == KIND_K2_FIRST && plan.passes[1].k->kind == KIND_K2_LATER)
+    // (three-pass plans: the same kernels fuse passes 0 and 1 over units, execute_fused; the third pass stays a launch of its own)
+    const bool two = plan.passes.size() == 2, three = plan.passes.size() == 3;
+    if (plan.kind == PLAN_MACRO && (two || three) && plan.passes[0].k->kind == KIND_K2_FIRST && plan.passes[1].k->kind == KIND_K2_LATER)
         for (auto& e : registry())
             if (e.kind == KIND_K2_FUSED && e.prec == plan.prec && !strcmp(e.part[0], plan.passes[0].k->name) && !strcmp(e.part[1], plan.passes[1].k->name) &&
                 (e.variant == 0 || (env_int("MI355FFT_FUSE_RING") && e.variant == 10 + env_int("MI355FFT_FUSE_RING") - 100))) {
+                if (three && (plan.passes[2].k->n % e.f != 0 || ((long long)plan.passes[0].k->n * e.f) % e.f2 != 0)) continue;
                 if (e.prepare()) return MI355FFT_ERR_HIP;
                 plan.fused = &e;
-                if (e.aux == 1 && env_int("MI355FFT_FUSE") == 0) plan.fuse_on = true;  // the measured default for this length
+                if (two && e.aux == 1 && env_int("MI355FFT_FUSE") == 0) plan.fuse_on = true;  // the measured default for this length
+                // three passes: measured for the 256 x 256 pairs (2^23 / 2^24: Complex<f32> +5 % / +3 %, Complex<f64> +21 %,
+                // profiles/r4/ab_fused3_*.jsonl); larger lengths have units beyond what the ring holds in the cache
+                if (three && e.aux == 1 && plan.len <= ((size_t)1 << 24) && env_int("MI355FFT_FUSE") == 0) plan.fuse_on = true;
                 if (e.variant != 0) break;  // tuning: the requested ring-access variant wins over the default
             }
     return MI355FFT_OK;
@@ -1211,7 +1235,8 @@ std::string Plan::describe() const {
     }
     if (fuse_on && fused) s << "fused{";
     for (size_t i = 0; i < passes.size(); ++i) {
-        s << (i ? (fuse_on && fused ? " | " : " -> ") : "") << passes[i].k->name;
+        if (i == 2 && fuse_on && fused) s << "}";  // three passes: the first two in one launch
+        s << (i ? (fuse_on && fused && i == 1 ? " | " : " -> ") : "") << passes[i].k->name;
         if (passes[i].k->kind == KIND_DYN_K1 || passes[i].k->kind == KIND_DYN_RADER) {
             const DynSched& d = passes[i].dyn;
             s << "<" << d.n << ", " << d.tpf;
@@ -1219,7 +1244,7 @@ std::string Plan::describe() const {
             s << ">xF" << d.f;
         }
     }
-    if (fuse_on && fused) s << "}";
+    if (fuse_on && fused && passes.size() == 2) s << "}";
     return s.str();
 }
 
@@ -1516,13 +1541,39 @@ template <class T> static int execute_pipelined(Plan& plan, const void* in, void
 // from how many transforms are in flight: F = ceil(workgroups the chip holds / tiles per step); lag = 2 F steps (the first-pass
 // tiles of a transform have long retired when its second-pass tiles come up), ns = 2 lag slots, at most 128 MiB (a slot is not
 // rewritten while a resident second-pass tile can still read it -- the counters enforce it; the slack only keeps anybody from waiting).
-template <class T> static int execute_fused(Plan& plan, const void* in, void* out, size_t batch, void* stream) {
+// Three-pass plans (N = R0 R1 R2, kernels_params.h): the same kernel fuses passes 0 and 1 over UNITS of F0 N / R2 elements (U = R2 / F0 per
+// transform, a ring slot holds one unit in compact form); `out` is then the buffer the third pass reads -- never the caller's input: a
+// unit's second-pass tiles write into a transform whose other units are still being read.
+template <class T> static int execute_fused(Plan& plan, const void* in, void* out, size_t batch, void* stream, bool have_lock) {
     const KernelEntry& k = *plan.fused;
     const size_t esz = 2 * sizeof(T), n = plan.len;
+    const bool three = plan.passes.size() == 3;
     K2FusedParams<T> fp{};
     if (int rc = fill_k2_params<T>(plan, 0, in, nullptr, batch, false, k.f, nullptr, nullptr, fp.pass[0])) return rc;
     if (int rc = fill_k2_params<T>(plan, 1, nullptr, out, batch, false, k.f2, nullptr, nullptr, fp.pass[1])) return rc;
-    const int t0 = (int)fp.pass[0].tiles_per_fft, t1 = (int)fp.pass[1].tiles_per_fft;
+    int t0 = (int)fp.pass[0].tiles_per_fft, t1 = (int)fp.pass[1].tiles_per_fft, units = 1;
+    if (three) {
+        const long long R0 = plan.passes[0].k->n, R2 = plan.passes[2].k->n;
+        if (R2 % k.f != 0 || (R0 * k.f) % k.f2 != 0) return MI355FFT_ERR_UNSUPPORTED;
+        units = (int)(R2 / k.f);
+        t0 /= units;                        // = R1
+        t1 = (int)(R0 * k.f / k.f2);        // second-pass tiles over the unit's F0 R0 columns
+        fp.pass[1].m = R0 * k.f;            // the ring slot as an (R1) x (F0 R0) matrix
+        K2Params<T>* ps[2] = {&fp.pass[0], &fp.pass[1]};
+        const int ts[2] = {t0, t1};
+        for (int q = 0; q < 2; ++q) {  // the XCD-aware order over the UNIT's tiles (fill_k2_params sized it for the transform's)
+            K2Params<T>& pq = *ps[q];
+            pq.tiles_per_fft = ts[q];
+            if (pq.xq > 0 || pq.xp > 0) {
+                int xq = 3;
+                while (xq > 0 && ts[q] % (8 << xq) != 0) --xq;
+                if (ts[q] % 8 != 0) xq = 0;
+                pq.xq = xq;
+                if (pq.xp > xq) pq.xp = xq;
+            }
+        }
+    }
+    const size_t steps = batch * (size_t)units, slot_elems = n / (size_t)units;
     const int resident = 256 * (k.threads >= 1024 ? 1 : 2);  // workgroups the chip holds (128 VGPRs: 16 waves per CU)
     const int inflight = (resident + t0 + t1 - 1) / (t0 + t1);
     // measured (profiles/r4/ab_fused_lag_2p*.jsonl): a lag of one in-flight window + 1 leaves second-pass tiles waiting (2^20: 11.3 ms
@@ -1530,14 +1581,15 @@ template <class T> static int execute_fused(Plan& plan, const void* in, void* ou
     // slots = 192 MiB: 12.2)
     int lag = plan.fuse_lag > 0 ? plan.fuse_lag : 2 * inflight;
     int ns = plan.fuse_slots > 0 ? plan.fuse_slots : 2 * lag;
-    while (plan.fuse_slots <= 0 && ns > lag + 1 && (size_t)ns * n * esz > ((size_t)128 << 20)) --ns;  // ring <= 128 MiB
+    while (plan.fuse_slots <= 0 && ns > lag + 1 && (size_t)ns * slot_elems * esz > ((size_t)128 << 20)) --ns;  // ring <= 128 MiB
     if (lag < 1) lag = 1;         // a second-pass tile waits for first-pass tiles of an EARLIER step (lower indices) only
     if (ns <= lag) ns = lag + 1;  // a first-pass tile of step s waits for second-pass tiles of step s - ns + lag: an earlier step as well
-    if (batch < (size_t)ns) return MI355FFT_ERR_UNSUPPORTED;  // fewer transforms than ring slots: nothing to overlap
+    if (steps < (size_t)ns) return MI355FFT_ERR_UNSUPPORTED;  // fewer steps than ring slots: nothing to overlap
     StreamSlot& slot = plan.slot_for(stream);
-    std::lock_guard<std::mutex> launch_lock(slot.launch_mutex);
+    std::unique_lock<std::mutex> launch_lock;
+    if (!have_lock) launch_lock = std::unique_lock<std::mutex>(slot.launch_mutex);
     PipeState& pp = slot.pipe;
-    const size_t need = (size_t)ns * n * esz, cbytes = (size_t)k2f_ctrl_words(ns) * sizeof(unsigned);
+    const size_t need = (size_t)ns * slot_elems * esz, cbytes = (size_t)k2f_ctrl_words(ns) * sizeof(unsigned);
     if (pp.ring.bytes < need || pp.ctrl_bytes < cbytes) {
         backend::sync(stream);
         if (pp.ring.bytes < need) {
@@ -1559,10 +1611,12 @@ template <class T> static int execute_fused(Plan& plan, const void* in, void* ou
     fp.tiles[1] = t1;
     fp.lag = lag;
     fp.ns = ns;
-    fp.batch = (long long)batch;
+    fp.batch = (long long)steps;
+    fp.units = units;
+    fp.slot_elems = (long long)slot_elems;
     fp.mode = plan.fuse_mode;
     fp.spin_limit = 1 << 21;  // x s_sleep(8) ~ 0.5 us each: about a second
-    const long long grid = k2f_grid((long long)batch, t0, t1, lag);
+    const long long grid = k2f_grid((long long)steps, t0, t1, lag);
     if (grid > kMaxGrid) return MI355FFT_ERR_INVALID_ARG;
     if (backend::memset_async(pp.ctrl, 0, cbytes, stream)) return MI355FFT_ERR_HIP;
     k.launch(&fp, grid, stream);
@@ -1661,7 +1715,7 @@ template <class T> static int execute_t(Plan& plan, const void* in, void* out, s
     const size_t P = plan.passes.size();
     if (P == 1) return launch_pass<T>(plan, 0, in, out, batch, stream, tr);
     if (plan.fuse_on && plan.fused && tr == nullptr && P == 2) {
-        const int rcf = execute_fused<T>(plan, in, out, batch, stream);
+        const int rcf = execute_fused<T>(plan, in, out, batch, stream, false);
         if (rcf != MI355FFT_ERR_UNSUPPORTED) return rcf;  // a batch too small to pipeline runs as two launches
     }
 #if defined(MI355_TUNING) || defined(MI355_EMU)
@@ -1741,7 +1795,17 @@ template <class T> static int execute_t(Plan& plan, const void* in, void* out, s
             B = (P % 2 == 0) ? ws : cout;
         }
         const char* src = cin;
-        for (size_t p = 0; p < P; ++p) {
+        size_t p0 = 0;
+        if (plan.fuse_on && plan.fused && tr == nullptr && P == 3 && plan.kind == PLAN_MACRO) {
+            // passes 0 and 1 in one launch, cin -> A (never back into the caller's input: see execute_fused); the third pass reads A
+            const int rcf = execute_fused<T>(plan, cin, A, cb, stream, need_ws);
+            if (rcf != MI355FFT_ERR_UNSUPPORTED) {
+                if (rcf) return rcf;
+                src = A;
+                p0 = 2;
+            }
+        }
+        for (size_t p = p0; p < P; ++p) {
             char* dstp = (p + 1 == P) ? cout : ((p % 2 == 0) ? A : B);
             int rc = launch_pass<T>(plan, p, src, dstp, cb, stream, tr);
             if (rc) return rc;

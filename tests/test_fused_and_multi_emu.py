@@ -41,6 +41,60 @@ def _with_env(env, fn):
                 os.environ[k] = v
 
 
+@pytest.mark.parametrize("dtype,log2n,maxr,batch", [(np.complex64, 22, 256, 2), (np.complex64, 23, 0, 1), (np.complex128, 23, 0, 1)])
+def test_fused_units_of_three_pass_plans(emu_lib, oracle, dtype, log2n, maxr, batch):
+    """Three-pass plans: passes 0 and 1 in one fused launch over UNITS (closed groups of R1 first-pass tiles and F0 R0 / F1 second-pass
+    tiles, kernels_params.h; a ring slot holds one unit in compact form, a tile reads and writes at different tile indices), the third
+    pass as its own launch.  2^22 as 256 x 256 x 64 (two units per transform), 2^23 as 256 x 256 x 128 (four; Complex<f64>: eight):
+    bit-identical to the three-launch plan in all three modes and both directions, the emulator's dependency check clean."""
+    n = 1 << log2n
+
+    def build(direction, fused):
+        f = _with_env({"MI355FFT_MAXR": maxr} if maxr else {}, lambda: _planner(emu_lib, dtype).plan_fft(n, direction))
+        f.set_fused(fused)
+        return f
+
+    x = random_signal(n * batch, dtype)
+    for direction in (0, 1):
+        ref, fus = build(direction, 0), build(direction, 1)
+        assert fus.is_fused() and fus.describe().startswith("fused{") and "} -> k2later" in fus.describe() and not ref.is_fused(), fus.describe()
+        a, b = x.copy(), x.copy()
+        ref.process(a)
+        fus.process(b)
+        assert np.array_equal(a, b) and fus.fused_status() == 0, (log2n, direction)
+        src, out = x.copy(), np.empty_like(x)
+        fus.process_immutable_with_scratch(src, out)
+        assert np.array_equal(out, a) and np.array_equal(src, x), (log2n, direction, "immutable")
+        fus.process_outofplace_with_scratch(src, out)
+        assert np.array_equal(out, a) and fus.fused_status() == 0, (log2n, direction, "out of place")
+        if direction == 0 and log2n == 22:
+            want = x[:n].copy()
+            oracle.plan(dtype, n, 0).process(want)
+            assert compare_vectors(want, b[:n])
+
+
+def test_planner_takes_the_split_with_a_default_fused_kernel(emu_lib):
+    """Two-pass plans whose balanced split has no default fused kernel while another split has one take that one (plan.cpp
+    choose_macro_radices): Complex<f32> 2^17 = 256 x 512 and 2^18 = 256 x 1024; three-pass 2^23 / 2^24 fuse their first two passes
+    by default; Complex<f64> 2^15 and 2^19 (whose fused kernel runs the plan's 8-column later tile as 16 columns) are fused by default."""
+    p32, p64 = _planner(emu_lib), _planner(emu_lib, np.complex128)
+    assert p32.plan_fft_forward(1 << 17).describe() == "fused{k2first<256, 16, 16, 16>xF32 | k2later<512, 16, 8, 8, 8>xF32t}"
+    assert p32.plan_fft_forward(1 << 18).describe() == "fused{k2first<256, 16, 16, 16>xF32 | k2later<1024, 32, 8, 8, 16>xF16t}"
+    assert p32.plan_fft_forward(1 << 23).describe().startswith("fused{k2first<256, 16, 16, 16>xF32 | k2later<256, 16, 16, 16>xF32} -> ")
+    assert p32.plan_fft_forward(1 << 24).describe().startswith("fused{")
+    assert not p32.plan_fft_forward(1 << 21).is_fused() and not p32.plan_fft_forward(1 << 25).is_fused()
+    for k in (15, 16, 17, 18, 19, 20, 23, 24):
+        assert p64.plan_fft_forward(1 << k).is_fused(), k
+    assert not p64.plan_fft_forward(1 << 21).is_fused()
+    x = random_signal((1 << 19) * 24, np.complex128)
+    fus, two = p64.plan_fft_forward(1 << 19), _planner(emu_lib, np.complex128).plan_fft_forward(1 << 19)
+    two.set_fused(0)
+    a, b = x.copy(), x.copy()
+    fus.process(a)
+    two.process(b)
+    assert np.array_equal(a, b) and fus.fused_status() == 0
+
+
 @pytest.mark.parametrize("log2n,lag,slots,batch", [(16, 1, 2, 5), (16, 2, 5, 7), (17, 1, 3, 4), (18, 1, 2, 3), (19, 1, 2, 3), (21, 1, 2, 2)])
 def test_fused_two_pass_launch_matches_two_launches(emu_lib, oracle, log2n, lag, slots, batch):
     """Every fused kernel against the two-launch plan of the same length, with a ring so small that slots are reused (a first-pass

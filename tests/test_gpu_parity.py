@@ -924,10 +924,12 @@ def test_host_slices_need_only_element_alignment_on_device(planners, oracle, dty
             assert rel_l2(dst, a) < 1e-6 and np.array_equal(src, x), (n, d, "immutable")
 
 
-@pytest.mark.parametrize("dtype,log2n", [(np.complex64, k) for k in (16, 17, 18, 19, 20, 21, 22)] + [(np.complex128, k) for k in (16, 17, 18, 20)])
+@pytest.mark.parametrize("dtype,log2n", [(np.complex64, k) for k in (16, 17, 18, 19, 20, 21, 22, 23, 24)] + [(np.complex128, k) for k in (15, 16, 17, 18, 19, 20, 23, 24)])
 def test_fused_two_pass_kernel_vs_oracle(planners, oracle, dtype, log2n):
     """The fused two-pass launch (one kernel, second pass of transform g - lag beside the first pass of transform g, the
-    intermediate through a cache-resident ring; launch.h k2f_kernel) for every length that has one, both precisions: rows across
+    intermediate through a cache-resident ring; launch.h k2f_kernel) for every length that has one, both precisions -- 2^23 and 2^24
+    are THREE-pass plans whose first two passes run fused over units of a transform (kernels_params.h), the third as a launch of its
+    own: rows across
     the whole batch against the oracle's Radix4 (src/algorithm/radix4.rs:167-203), the whole batch against the two-launch plan of
     the same kernels, the dependency error word, all three device entry points, both directions.  (Complex<f64> stores the ring
     with an inline-asm 16-byte write-through store: its missing hazard pad produced wrong results on the device at 2^17, 2^18 and
@@ -968,11 +970,16 @@ def test_fused_two_pass_kernel_vs_oracle(planners, oracle, dtype, log2n):
         src = x.clone()
         fus.process_outofplace_with_scratch(src, out)
         assert torch.equal(torch.view_as_real(out), torch.view_as_real(b)) and fus.fused_status() == 0, (log2n, d, "out of place")
-        # a batch smaller than the ring runs as two launches: identical to the two-launch plan
+        # a batch smaller than the ring runs as two launches: identical to the two-launch plan (three-pass plans: two transforms are
+        # 8 - 32 units, more than the ring has slots -- the fused launch runs, equal up to rounding as above)
         c, e = x[: 2 * n].clone(), x[: 2 * n].clone()
         fus.process(c)
         two.process(e)
-        assert torch.equal(torch.view_as_real(c), torch.view_as_real(e)), (log2n, d, "small batch")
+        if log2n < 23:
+            assert torch.equal(torch.view_as_real(c), torch.view_as_real(e)), (log2n, d, "small batch")
+        else:
+            err = (torch.view_as_real(c) - torch.view_as_real(e)).abs().max().item()
+            assert err <= (4e-7 if dtype == np.complex64 else 1e-15) * torch.view_as_real(e).abs().max().item() and fus.fused_status() == 0, (log2n, d, "small batch", err)
 
 
 def test_fused_kernel_repeatable_under_load_and_across_streams(planners):
