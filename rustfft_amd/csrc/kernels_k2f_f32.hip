@@ -27,6 +27,10 @@ void register_k2f_f32(std::vector<KernelEntry>& reg) {
     MI_K2F(1, float, 32, "k2first<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024, "k2later<512, 16, 8, 8, 8>xF32t", 32, true, 128, S512L);   // 2^19
     MI_K2F(1, float, 32, "k2first<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024, "k2later<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024); // 2^20
     MI_K2F(0, float, 32, "k2first<2048, 64, 8, 16, 16>xF8", 8, true, 0, S2048, "k2later<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024);     // 2^21
+    // 2^21 as 1024 x 2048, the later pass on 8-column tiles of 512 threads (the plan's later tile has 16 columns on 1024 threads; one launch
+    // has one block size): 7.00 ms (2048 x 1024, two launches) -> 6.49 (+7.8 %, profiles/r4/ab_fused_rev_2p21.jsonl); the planner takes
+    // this split because it is the one with a default fused kernel.  (The standard order below spills in its 2048-row first tile: -4 %.)
+    MI_K2F(1, float, 32, "k2first<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024, "k2later<2048, 128, 8, 16, 16>xF16p2", 8, true, 0, S2048);
     MI_K2FR(0, float, 32, "k2first<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024, "k2later<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024);
     MI_K2FR(3, float, 32, "k2first<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024, "k2later<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024);
     // 2^22: the one-pass plan runs its second pass on 16-column tiles of 1024 threads; a fused launch has ONE block size, so

@@ -1,5 +1,5 @@
 // Fused two-pass kernels (launch.h k2f_kernel), Complex<double>: the two-pass power-of-two plans whose two tiles run on the same
-// number of threads (2^15 ... 2^20; 2^19's later tile in a wider shape than the plan's; 2^21 pairs a 1024-thread tile with a 512-thread one).
+// number of threads (2^15 ... 2^21; the later tiles of 2^19 and 2^21 in a wider shape than the plan's).
 // The 256 x 256 pair also fuses the first two passes of the three-pass plans 2^23 and 2^24 (+21 % / +8 %, ab_fused3_f64_2p2*.jsonl).  First macro
 // argument: 1 = the planner's default: with ONE 16-byte write-through store per element (cx.h st_agent) the fused launch gains
 // 20 % / 14 % / 12 % / 26 % at 2^16 / 2^17 / 2^18 / 2^20, results bit-identical to the two-launch plan
@@ -21,5 +21,11 @@ void register_k2f_f64(std::vector<KernelEntry>& reg) {
     MI_K2F(1, double, 64, "k2first<512, 32, 16, 8, 4>xF8", 8, false, 0, S512, "k2later<256, 16, 16, 16>xF16", 16, false, 0, S256);                     // 2^17
     MI_K2F(1, double, 64, "k2first<512, 32, 16, 8, 4>xF8", 8, false, 0, S512, "k2later<512, 32, 16, 8, 4>xF8", 8, false, 0, S512);                      // 2^18
     MI_K2F(1, double, 64, "k2first<1024, 64, 16, 16, 4>xF8t1", 8, true, 1024, S1024F, "k2later<1024, 64, 8, 8, 16>xF8t1", 8, true, 1024, S1024L);     // 2^20
+    // 2^21: the 1024-row later tile as 16 columns on 1024 threads (the plan's has 8 on 512; the 2048-row first tile needs 1024):
+    // 6.77 -> 6.46 ms (+4.8 %, profiles/r4/ab_fused_f64_2p21.jsonl).  Measured and not compiled: 2^21 as 1024 x 2048 with a 4-column later
+    // tile on 512 threads +2 % (ab_fused_rev_f64_2p21.jsonl); 2^22, both 2048-row tiles on 1024 threads, one workgroup per CU: -11 %
+    // (ab_fused_f64_2p22.jsonl)
+    using S2048 = Sched<2048, 128, 16, 16, 8>;
+    MI_K2F(1, double, 64, "k2first<2048, 128, 16, 16, 8>xF8", 8, true, 0, S2048, "k2later<1024, 64, 8, 8, 16>xF8t1", 16, true, 1024, S1024L);        // 2^21
 }
 }  // namespace mi355

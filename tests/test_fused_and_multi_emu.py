@@ -75,17 +75,18 @@ def test_fused_units_of_three_pass_plans(emu_lib, oracle, dtype, log2n, maxr, ba
 
 def test_planner_takes_the_split_with_a_default_fused_kernel(emu_lib):
     """Two-pass plans whose balanced split has no default fused kernel while another split has one take that one (plan.cpp
-    choose_macro_radices): Complex<f32> 2^17 = 256 x 512 and 2^18 = 256 x 1024; three-pass 2^23 / 2^24 fuse their first two passes
+    choose_macro_radices): Complex<f32> 2^17 = 256 x 512, 2^18 = 256 x 1024 and 2^21 = 1024 x 2048; three-pass 2^23 / 2^24 fuse their first two passes
     by default; Complex<f64> 2^15 and 2^19 (whose fused kernel runs the plan's 8-column later tile as 16 columns) are fused by default."""
     p32, p64 = _planner(emu_lib), _planner(emu_lib, np.complex128)
     assert p32.plan_fft_forward(1 << 17).describe() == "fused{k2first<256, 16, 16, 16>xF32 | k2later<512, 16, 8, 8, 8>xF32t}"
     assert p32.plan_fft_forward(1 << 18).describe() == "fused{k2first<256, 16, 16, 16>xF32 | k2later<1024, 32, 8, 8, 16>xF16t}"
     assert p32.plan_fft_forward(1 << 23).describe().startswith("fused{k2first<256, 16, 16, 16>xF32 | k2later<256, 16, 16, 16>xF32} -> ")
     assert p32.plan_fft_forward(1 << 24).describe().startswith("fused{")
-    assert not p32.plan_fft_forward(1 << 21).is_fused() and not p32.plan_fft_forward(1 << 25).is_fused()
-    for k in (15, 16, 17, 18, 19, 20, 23, 24):
+    assert p32.plan_fft_forward(1 << 21).describe() == "fused{k2first<1024, 32, 8, 8, 16>xF16t | k2later<2048, 128, 8, 16, 16>xF16p2}"
+    assert not p32.plan_fft_forward(1 << 22).is_fused() and not p32.plan_fft_forward(1 << 25).is_fused()
+    for k in (15, 16, 17, 18, 19, 20, 21, 23, 24):
         assert p64.plan_fft_forward(1 << k).is_fused(), k
-    assert not p64.plan_fft_forward(1 << 21).is_fused()
+    assert not p64.plan_fft_forward(1 << 22).is_fused()
     x = random_signal((1 << 19) * 24, np.complex128)
     fus, two = p64.plan_fft_forward(1 << 19), _planner(emu_lib, np.complex128).plan_fft_forward(1 << 19)
     two.set_fused(0)
@@ -98,8 +99,14 @@ def test_planner_takes_the_split_with_a_default_fused_kernel(emu_lib):
 @pytest.mark.parametrize("log2n,lag,slots,batch", [(16, 1, 2, 5), (16, 2, 5, 7), (17, 1, 3, 4), (18, 1, 2, 3), (19, 1, 2, 3), (21, 1, 2, 2)])
 def test_fused_two_pass_launch_matches_two_launches(emu_lib, oracle, log2n, lag, slots, batch):
     """Every fused kernel against the two-launch plan of the same length, with a ring so small that slots are reused (a first-pass
-    tile has to find its slot read, a second-pass tile its slot written): bit-identical results, error word 0."""
+    tile has to find its slot read, a second-pass tile its slot written): bit-identical results, error word 0.  (2^21: the fused
+    kernel runs the later pass on 8-column tiles of 64 threads per column where the plan's own tile has 128 -- another chain of
+    inter-pass factor products, so equal up to rounding only.)"""
     n = 1 << log2n
+
+    def same(u, v):
+        return np.array_equal(u, v) if log2n != 21 else float(np.abs(u - v).max()) <= 4e-7 * float(np.abs(v).max())
+
     ref = _planner(emu_lib).plan_fft_forward(n)
     ref.set_fused(0)
     fus = _with_env({"MI355FFT_FUSE_LAG": lag, "MI355FFT_FUSE_SLOTS": slots}, lambda: _planner(emu_lib).plan_fft_forward(n))
@@ -109,7 +116,7 @@ def test_fused_two_pass_launch_matches_two_launches(emu_lib, oracle, log2n, lag,
     a, b = x.copy(), x.copy()
     ref.process(a)
     fus.process(b)
-    assert np.array_equal(a, b)
+    assert same(a, b)
     assert fus.fused_status() == 0
     want = x[:n].copy()
     oracle.plan(np.complex64, n, 0).process(want)
@@ -117,10 +124,10 @@ def test_fused_two_pass_launch_matches_two_launches(emu_lib, oracle, log2n, lag,
     # the other two API modes run the same launch: the input is never clobbered
     y = np.empty_like(x)
     fus.process_immutable_with_scratch(x, y)
-    assert np.array_equal(y, a)
+    assert np.array_equal(y, b)
     x2, y2 = x.copy(), np.empty_like(x)
     fus.process_outofplace_with_scratch(x2, y2)
-    assert np.array_equal(y2, a) and fus.fused_status() == 0
+    assert np.array_equal(y2, b) and fus.fused_status() == 0
 
 
 def test_fused_default_ring_and_small_batches(emu_lib):
