@@ -376,7 +376,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=4)  # (a fused plan reaches its steady rate after ~10 launches of a fresh process: profiles/r4/fused_warmup_*.jsonl)
+    ap.add_argument("--warmup", type=int, default=8)  # (a fused plan reaches its steady rate after ~10 launches of a fresh process: profiles/r4/fused_warmup_*.jsonl; a step is two launches)
     ap.add_argument("--log2n", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1024, help="transforms per GPU")
     ap.add_argument("--chunk", type=int, default=-1, help="transforms per workspace chunk (-1 = library default)")
@@ -451,7 +451,7 @@ def main():
     # region.  Longer runs renormalise between steps with the clock stopped (synchronised on both sides, counted in
     # `renorm_pauses`), so the timed region contains the K forward+inverse pairs and nothing else.
     span = max(1, 224 // args.log2n)
-    done = 0  # (default warmup 4 + steps 8 exceed the span of 11 at 2^20 once: one clock-stopped renormalisation)
+    done = 0
 
     def renorm_if_needed():
         nonlocal done
@@ -475,6 +475,10 @@ def main():
     for i in range(args.warmup):
         renorm_if_needed()
         step()
+    # back to the starting magnitudes before the clock starts: the default K = 8 steps then fit the span without a pause
+    for _ in range(((done - 1) % span) + 1 if done else 0):  # the steps since the last renormalisation (it runs in front of a step)
+        data.mul_(1.0 / n)
+    done = 0
     torch.cuda.synchronize()
     if dist:
         dist.barrier()

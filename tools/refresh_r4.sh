@@ -16,8 +16,8 @@ for c in c4 c5; do
   cp $(find /tmp/prof_$c -name "*kernel_stats.csv" | head -1) $OUT/bench_${c}_kernel_stats.csv 2>/dev/null
 done
 python tools/sweep.py --dtype f32 --min 10 --max 24 --bytes 4 --check > $OUT/sweep_pow2_f32_4GiB.jsonl 2>/dev/null
-python tools/sweep.py --dtype f32 --min 16 --max 22 --bytes 4 --fused 0 > $OUT/sweep_pow2_f32_4GiB_two_launch.jsonl 2>/dev/null
-python tools/sweep.py --dtype f64 --min 10 --max 23 --bytes 4 --check > $OUT/sweep_pow2_f64_4GiB.jsonl 2>/dev/null
+python tools/sweep.py --dtype f32 --min 16 --max 24 --bytes 4 --fused 0 > $OUT/sweep_pow2_f32_4GiB_two_launch.jsonl 2>/dev/null
+python tools/sweep.py --dtype f64 --min 10 --max 24 --bytes 4 --check > $OUT/sweep_pow2_f64_4GiB.jsonl 2>/dev/null
 NP2=3,7,17,77,100,127,251,289,360,719,899,1000,1001,1009,1019,1200,1201,1517,2003,2310,3000,4093,4099,4875,5000,5082,6006,8633,10000,10007,10403,12289,19683,20449,25000,41959,44100,45056,65231,65537,100000,100003,158381,216569,417623,1000000,1000003,1536000,7340032
 python tools/sweep.py --dtype f32 --sizes $NP2 --check > $OUT/sweep_np2_f32.jsonl 2>/dev/null
 python tools/sweep.py --dtype f64 --sizes $NP2 --check > $OUT/sweep_np2_f64.jsonl 2>/dev/null
