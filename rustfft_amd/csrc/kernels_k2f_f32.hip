@@ -31,6 +31,17 @@ void register_k2f_f32(std::vector<KernelEntry>& reg) {
     // has one block size): 7.00 ms (2048 x 1024, two launches) -> 6.49 (+7.8 %, profiles/r4/ab_fused_rev_2p21.jsonl); the planner takes
     // this split because it is the one with a default fused kernel.  (The standard order below spills in its 2048-row first tile: -4 %.)
     MI_K2F(1, float, 32, "k2first<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024, "k2later<2048, 128, 8, 16, 16>xF16p2", 8, true, 0, S2048);
+#if defined(MI355_TUNING)
+    // other splits of 2^16 ... 2^20 (MI355FFT_R0 selects them): candidates
+    using S128 = Sched<128, 8, 16, 8>;
+    MI_K2F(0, float, 32, "k2first<128, 8, 16, 8>xF64", 64, false, 0, S128, "k2later<512, 16, 8, 8, 8>xF32t", 32, true, 128, S512L);            // 2^16 = 128 x 512
+    MI_K2F(0, float, 32, "k2first<512, 32, 16, 8, 4>xF16t", 16, false, 128, S512F, "k2later<128, 8, 16, 8>xF64t", 64, false, 128, S128);      // 2^16 = 512 x 128
+    MI_K2F(0, float, 32, "k2first<128, 8, 16, 8>xF64", 64, false, 0, S128, "k2later<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024);         // 2^17 = 128 x 1024
+    MI_K2F(0, float, 32, "k2first<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024, "k2later<128, 8, 16, 8>xF64t", 64, false, 128, S128);      // 2^17 = 1024 x 128
+    MI_K2F(0, float, 32, "k2first<128, 8, 16, 8>xF64", 64, false, 0, S128, "k2later<2048, 128, 8, 16, 16>xF16p2", 8, true, 0, S2048);         // 2^18 = 128 x 2048
+    MI_K2F(0, float, 32, "k2first<256, 16, 16, 16>xF32", 32, false, 0, S256, "k2later<2048, 128, 8, 16, 16>xF16p2", 8, true, 0, S2048);       // 2^19 = 256 x 2048
+    MI_K2F(0, float, 32, "k2first<512, 32, 16, 8, 4>xF16t", 16, false, 128, S512F, "k2later<2048, 128, 8, 16, 16>xF16p2", 8, true, 0, S2048);  // 2^20 = 512 x 2048
+#endif
     MI_K2FR(0, float, 32, "k2first<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024, "k2later<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024);
     MI_K2FR(3, float, 32, "k2first<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024, "k2later<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024);
     // 2^22: the one-pass plan runs its second pass on 16-column tiles of 1024 threads; a fused launch has ONE block size, so
