@@ -558,7 +558,7 @@ def main():
             per_kernel.append({"kernel": nm, "ms": ms, "GBps": alg_bytes / (ms * 1e-3) / 1e9})
         dom = max(per_kernel, key=lambda r: r["ms"])
         two_launch_frac = (batch * 2 * n * 8) / (sum(r["ms"] for r in per_kernel) * 1e-3) / 1e9 / HBM_PEAK_GBS
-        if fwd.is_fused():
+        if fwd.is_fused() and len(names) == 2:
             # The timed region ran ONE launch per direction (both passes fused, the intermediate through a cache-resident ring):
             # its duration from HIP events on the launch stream (torch's current stream is the stream the library launches on).
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -597,6 +597,8 @@ def main():
                                "algorithmic_bytes_per_launch": alg_bytes,
                                "kernels": per_kernel,
                                "transform_algorithmic_frac": two_launch_frac}
+            if fwd.is_fused():  # a three-pass plan: the timed region ran passes 0 + 1 as one launch; the figures here are the passes alone
+                out["roofline"]["note"] = "three-pass plan whose first two passes run fused in the timed region; per-kernel figures: each pass as its own launch"
         try:
             import ctypes
 

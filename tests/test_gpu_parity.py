@@ -982,15 +982,17 @@ def test_fused_two_pass_kernel_vs_oracle(planners, oracle, dtype, log2n):
             assert err <= (4e-7 if dtype == np.complex64 else 1e-15) * torch.view_as_real(e).abs().max().item() and fus.fused_status() == 0, (log2n, d, "small batch", err)
 
 
-def test_fused_kernel_repeatable_under_load_and_across_streams(planners):
+@pytest.mark.parametrize("log2n,batch", [(20, 256), (21, 128), (23, 32)])
+def test_fused_kernel_repeatable_under_load_and_across_streams(planners, log2n, batch):
     """A stale read of the ring (a missing acquire, a slot rewritten too early) shows up as a run-to-run difference long before it
     breaks a tolerance: 30 fused transforms of one input, odd ones beside a copy stream that hammers HBM, must agree bit for
-    bit; then two host threads drive the same plan on their own streams (own rings) concurrently."""
+    bit; then two host threads drive the same plan on their own streams (own rings) concurrently.  2^20: the two-pass launch; 2^21:
+    the re-split plan with the narrow later tile; 2^23: units of a three-pass plan (ring of 4 slots, each reused 32 times per call)."""
     import torch
 
     import rustfft_amd
 
-    n, batch = 1 << 20, 256
+    n = 1 << log2n
     fft = rustfft_amd.FftPlanner(np.complex64).plan_fft_forward(n)
     assert fft.is_fused()
     x = torch.empty(batch * n, dtype=torch.complex64, device="cuda")
