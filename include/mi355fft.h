@@ -249,14 +249,14 @@ int mi355fft_profile_inplace_dev(const mi355fft_plan* plan, void* buffer, size_t
  * pattern that reaches the chip's measured 6.2 - 6.3 TB/s): the data-movement ceiling bench.py quotes next to the 8 TB/s
  * spec.  Allocates and frees two scratch buffers of that size. */
 int mi355fft_measure_copy_ceiling(size_t bytes, double* gbps);
-/* Fused two-pass launches.  A two-pass power-of-two plan (2^16 .. 2^22 in Complex<f32>) can run BOTH column-tile passes in
- * one launch: the second pass of transform g - lag runs beside the first pass of transform g, and the intermediate goes
+/* Fused two-pass launches.  A two-pass power-of-two plan (2^16 .. 2^22 in Complex<f32>, 2^15 .. 2^21 in Complex<f64>) can run BOTH
+ * column-tile passes in one launch (a three-pass plan -- 2^23, 2^24 -- its first two, over units of a transform): the second pass of transform g - lag runs beside the first pass of transform g, and the intermediate goes
  * through a ring of a few transform-sized slots that stays in the Infinity Cache, so HBM sees one read and one write per
  * transform instead of two (the reference's own structure, for comparison: Radix4 / MixedRadix sweep the whole buffer once
  * per level, src/algorithm/radix4.rs:167-203).  The planner uses it where an on-device A/B measured a gain; this setter
  * overrides that: -1 = the planner's choice (default), 0 = never, 1 = whenever a fused kernel exists for the plan.
  * Batches with fewer transforms than the ring has slots always run as two launches.  Results are those of the two-launch
- * plan up to the rounding of differently contracted multiply-adds (same kernel bodies). */
+ * plan up to rounding (the same kernel bodies compiled into another kernel; at two lengths the later tile in another shape). */
 int mi355fft_plan_set_fused(mi355fft_plan* plan, int mode);
 /* 1 when process_* calls of this plan currently use a fused launch (for a large enough batch), else 0. */
 int mi355fft_plan_is_fused(const mi355fft_plan* plan);

@@ -1,9 +1,10 @@
 // Fused two-pass kernels (launch.h k2f_kernel): both column-tile passes of a two-pass power-of-two plan in ONE launch, the
-// intermediate in a cache-resident ring.  One entry per two-pass plan 2^16 .. 2^22, Complex<float>; each names the two
+// intermediate in a cache-resident ring.  One entry per two-pass plan 2^16 .. 2^22, Complex<float> (the 256 x 256 pair also fuses the first two passes of the three-pass plans 2^23 and 2^24
+// over units of a transform: kernels_params.h); each names the two
 // one-pass kernels (kernels_k2_f32.hip) whose tiles it runs.  First macro argument: 1 = the planner's default for that length
 // (interleaved A/B against the two-launch plan, three plan instances per arm, the final lag / ring rule,
 // profiles/r4/ab_fused_final_2p*.jsonl: 2^16 +10.9 %, 2^19 +13.6 %, 2^20 +18.3 % (12.66 -> 10.71 ms per forward + inverse pair); steady-state
-// forward-only launches at 4 GiB, profiles/r4/fused_warmup_2p*.jsonl: 2^16 +8 %, 2^17 +11 %, 2^19 +14 %, 2^20 +11 %, 2^18 +-0 -- 2^18 stays off;
+// forward-only launches at 4 GiB, profiles/r4/fused_warmup_2p*.jsonl: 2^16 +8 %, 2^17 +11 %, 2^19 +14 %, 2^20 +11 %, 2^18 (512 x 512) +-0 -- that split stays off, 2^18 runs as 256 x 1024 (below);
 // 2^21 -4 %, 2^22 -13 % -- the 2048-row tiles spill in the fused kernel and 2^22's second pass has to run on 8-column tiles).
 #include "launch.h"
 #include "kernel_lists.h"
