@@ -48,7 +48,21 @@ int h2d(void* d, const void* h, size_t bytes, void* s) { return fail(hipMemcpyAs
 int d2h(void* h, const void* d, size_t bytes, void* s) { return fail(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)s)); }
 int d2d(void* dst, const void* src, size_t bytes, void* s) { return fail(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s)); }
 int sync(void* s) { return fail(hipStreamSynchronize((hipStream_t)s)); }
-int memset_async(void* d, int value, size_t bytes, void* s) { return fail(hipMemsetAsync(d, value, bytes, (hipStream_t)s)); }
+// (a kernel, not hipMemsetAsync: under stream capture a memset node did not reliably order in front of the next kernel node -- a
+// fused launch replayed from a HIP graph next to another one found its control block unzeroed and did nothing; kernel -> kernel
+// dependencies are what every captured launch of this library already relies on.  tests: test_device_calls_capture_into_a_hip_graph)
+__global__ void fill_words_kernel(unsigned* p, unsigned v, size_t words) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < words) p[i] = v;
+}
+int memset_async(void* d, int value, size_t bytes, void* s) {
+    if (bytes % 4 != 0 || ((size_t)d & 3) != 0) return fail(hipMemsetAsync(d, value, bytes, (hipStream_t)s));
+    const unsigned b = (unsigned)value & 0xffu, v = b | (b << 8) | (b << 16) | (b << 24);
+    const size_t words = bytes / 4;
+    if (words == 0) return 0;
+    fill_words_kernel<<<dim3((unsigned)((words + 255) / 256)), dim3(256), 0, (hipStream_t)s>>>((unsigned*)d, v, words);
+    return fail(hipGetLastError());
+}
 int memcpy_peer(void* dst, int dst_device, const void* src, int src_device, size_t bytes, void* s) {
     if (dst_device == src_device) return fail(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)s));
     return fail(hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, (hipStream_t)s));

@@ -1036,6 +1036,49 @@ def test_fused_kernel_repeatable_under_load_and_across_streams(planners, log2n, 
         assert torch.equal(torch.view_as_real(first), torch.view_as_real(y))
 
 
+@pytest.mark.parametrize("n,batch", [(1024, 512), (1009, 256), (4099, 64), (45056, 32), (1 << 16, 96), (1 << 20, 40), (1 << 22, 8), (1 << 23, 8)])
+def test_device_calls_capture_into_a_hip_graph(planners, n, batch):
+    """The device entry points are stream-ordered and make no host-side synchronisation once a plan's workspaces exist (after one
+    warm-up call on the stream): a forward + inverse pair captured into a HIP graph (hipStreamBeginCapture through torch.cuda.graph)
+    replays with the results of the direct calls -- whole-row kernel, Rader, Bluestein, general passes, the fused launch (a memset node
+    and a kernel node), two launches through a workspace, and the unit launch of a three-pass plan."""
+    import torch
+
+    import rustfft_amd
+
+    planner = rustfft_amd.FftPlanner(np.complex64)
+    fwd, inv = planner.plan_fft_forward(n), planner.plan_fft_inverse(n)
+    x = torch.empty(batch * n, dtype=torch.complex64, device="cuda")
+    torch.view_as_real(x).uniform_(-1.0, 1.0)
+    want = x.clone()
+    fwd.process(want)
+    torch.cuda.synchronize()
+    want_pair = want.clone()
+    inv.process(want_pair)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    buf, mid = x.clone(), torch.empty_like(x)
+    with torch.cuda.stream(s):
+        tmp = x.clone()
+        fwd.process(tmp)  # warm-up on the capture stream: workspaces and rings are allocated (and synchronised) here, not under capture
+        inv.process(tmp)
+    s.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        fwd.process(buf)
+        mid.copy_(buf)
+        inv.process(buf)
+    for _ in range(3):
+        buf.copy_(x)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(torch.view_as_real(mid), torch.view_as_real(want)), (n, "forward")
+        assert torch.equal(torch.view_as_real(buf), torch.view_as_real(want_pair)), (n, "pair")
+    if fwd.is_fused():
+        assert fwd.fused_status() == 0 and inv.fused_status() == 0
+
+
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_multi_device_plan_on_one_gpu(planners, oracle, dtype):
     """mi355fft_multi_plan with the device list [0, 0] (two shards, two replicas, two worker threads and staging pools on the one
