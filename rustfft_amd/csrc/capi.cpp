@@ -428,7 +428,7 @@ int mi355fft_measure_copy_ceiling(size_t bytes, double* gbps) {
 int mi355fft_plan_set_fused(mi355fft_plan* plan, int mode) {
     if (!plan || mode < -1 || mode > 1) return set_err(MI355FFT_ERR_INVALID_ARG, "bad fused mode");
     Plan& p = plan->p;
-    p.fuse_on = p.fused && (mode == 1 || (mode == -1 && p.fused->aux == 1));
+    p.fuse_on = p.fused && (mode == 1 || (mode == -1 && p.fuse_default));
     return MI355FFT_OK;
 }
 int mi355fft_plan_is_fused(const mi355fft_plan* plan) { return plan && plan->p.fuse_on && plan->p.fused ? 1 : 0; }

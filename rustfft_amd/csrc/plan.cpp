@@ -1215,6 +1215,7 @@ int build_plan(Plan& plan) {
                 // three passes: measured for the 256 x 256 pairs (2^23 / 2^24: Complex<f32> +5 % / +3 %, Complex<f64> +21 %,
                 // profiles/r4/ab_fused3_*.jsonl); larger lengths have units beyond what the ring holds in the cache
                 if (three && e.aux == 1 && plan.len <= ((size_t)1 << 24) && env_int("MI355FFT_FUSE") == 0) plan.fuse_on = true;
+                plan.fuse_default = (two && e.aux == 1) || (three && e.aux == 1 && plan.len <= ((size_t)1 << 24));
                 if (e.variant != 0) break;  // tuning: the requested ring-access variant wins over the default
             }
     return MI355FFT_OK;

@@ -100,6 +100,7 @@ struct Plan {
     // execute() uses it, its protocol mode (K2FusedParams::mode) and, for experiments, lag / ring slots (0 = derived)
     const KernelEntry* fused = nullptr;
     bool fuse_on = false;
+    bool fuse_default = false;  // the planner's measured choice for this plan (mi355fft_plan_set_fused(-1) restores it)
     int fuse_mode = 3, fuse_lag = 0, fuse_slots = 0;  // mode 3: dependency counters + work items by ticket
     // mi355fft_plan_options (host planner in charge): algorithm family, twiddle source, finished tables
     int algorithm = 0;

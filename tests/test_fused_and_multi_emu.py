@@ -84,6 +84,14 @@ def test_planner_takes_the_split_with_a_default_fused_kernel(emu_lib):
     assert p32.plan_fft_forward(1 << 24).describe().startswith("fused{")
     assert p32.plan_fft_forward(1 << 21).describe() == "fused{k2first<1024, 32, 8, 8, 16>xF16t | k2later<2048, 128, 8, 16, 16>xF16p2}"
     assert not p32.plan_fft_forward(1 << 22).is_fused() and not p32.plan_fft_forward(1 << 25).is_fused()
+    big = p32.plan_fft_forward(1 << 26)  # 512 x 512 x 256: a fused kernel exists for the first two passes, the planner's choice is "no"
+    for mode, want in ((1, True), (-1, False), (0, False)):
+        big.set_fused(mode)
+        assert big.is_fused() == want, mode
+    mid = p32.plan_fft_forward(1 << 23)
+    for mode, want in ((0, False), (-1, True)):
+        mid.set_fused(mode)
+        assert mid.is_fused() == want, mode
     for k in (15, 16, 17, 18, 19, 20, 21, 23, 24):
         assert p64.plan_fft_forward(1 << k).is_fused(), k
     assert not p64.plan_fft_forward(1 << 22).is_fused()
