@@ -1,0 +1,23 @@
+// One-kernel and two-kernel Bluestein bodies, Complex<float>, over the 2^k and 3 * 2^k inner lengths (the 5 * 2^k / 7 * 2^k ones:
+// kernels_bs57_f32.hip).  This unit and kernels_bs57_f32.hip are compiled with -fno-slp-vectorize (Makefile NOSLP): the SLP vectoriser
+// pairs the re / im parts of DIFFERENT values into v_pk_*_f32 operations and pays for the pairing in register moves (a quarter of the
+// VALU instructions of these bodies); without it every inner length listed here runs 1 ... 9.5 % faster (416 primes <= 4096: median
+// +4.9 %; the two-kernel pair at n = 10007: +25 %; profiles/r4/ab_noslp_*.jsonl).  2048 and 1792 lose and stay in kernels_np2_f32.hip.
+#define MI355_PK_CMUL 1
+#include "launch.h"
+#include "kernel_lists.h"
+namespace mi355 {
+void register_bs_f32(std::vector<KernelEntry>& reg) {
+    MI_BS_LIST(float, 32);
+    MI_BS(float, 32, 4, 512, 64, 8, 8, 8);
+    MI_BS(float, 32, 1, 1024, 128, 8, 8, 16);  // 3.98 ns per row against 4.25 for 16 x 16 x 4 on one wave
+    MI_BS(float, 32, 1, 8192, 512, 16, 16, 32);  // 1.22 TB/s against 0.97 for 16 x 8 x 8 x 8 (one exchange fewer)
+    MI_BS_LIST3_F32(float, 32);
+    // one-kernel Bluestein for 4096 < n <= 8192 through the split exchange, two-kernel Bluestein for 8192 < n <= 16384 (see kernels_k1_f32.hip
+    // for the measurements behind the split)
+    MI_BSS(float, 32, 1, 12288, 768, 12, 8, 8, 16);   // four lighter sub-passes: 100.5 ns per row against 115.4 for 32 x 24 x 16 on 512 threads
+    MI_BSS(float, 32, 1, 16384, 1024, 8, 8, 16, 16);  // 111.8 against 125.0 for 16 x 32 x 32 on 512 threads
+    MI_BS2(float, 32, 1, true, 24576, 1024, 32, 32, 24);
+    MI_BS2(float, 32, 1, true, 32768, 1024, 32, 32, 32);
+}
+}  // namespace mi355

@@ -48,13 +48,10 @@ void register_k1_f32(std::vector<KernelEntry>& reg) {
     // one-kernel Bluestein for 4096 < n <= 8192: split exchange, spectrum handed over in registers (measured 626 / 1020 GB/s at
     // n = 4099 / 7919 against 470 / 690 for the two-kernel form; the 1024-thread bodies for M = 24576, 32768 spill under the
     // 128-VGPR cap and lose to it: 458 against 642 at n = 10007, so 8192 < n <= 16384 keeps two kernels)
-    MI_BSS(float, 32, 1, 12288, 768, 12, 8, 8, 16);   // four lighter sub-passes: 100.5 ns per row against 115.4 for 32 x 24 x 16 on 512 threads
-    MI_BSS(float, 32, 1, 16384, 1024, 8, 8, 16, 16);  // 111.8 against 125.0 for 16 x 32 x 32 on 512 threads
+    // (the production bodies for 12288 / 16384 and the two-kernel pair: kernels_bs_f32.hip, compiled without the SLP vectoriser)
     MI_BSSV(1, float, 32, 1, 12288, 512, 32, 24, 16);  // tuning: the schedules these replaced; (2): without the split exchange
     MI_BSSV(1, float, 32, 1, 16384, 512, 16, 32, 32);
     MI_BSV(2, float, 32, 1, 16384, 512, 16, 32, 32);
-    MI_BS2(float, 32, 1, true, 24576, 1024, 32, 32, 24);
-    MI_BS2(float, 32, 1, true, 32768, 1024, 32, 32, 32);
     MI_K1V(4, float, 32, 1, true, 8192, 512, 16, 8, 8, 8);
     // tuning: lighter sub-passes / more threads for the whole-row kernels (tools/ab.py --log2n k min:MI355FFT_VARIANT=v)
     MI_K1V(5, float, 32, 1, false, 4096, 512, 8, 8, 8, 8);

@@ -51,12 +51,11 @@ void register_np2_f32(std::vector<KernelEntry>& reg) {
     MI_RADERV(6, float, 32, 8, 6, 540, 108, 12, 9, 5);
     MI_RADERV(6, float, 32, 8, 6, 4050, 450, 10, 9, 9, 5);
     MI_RADERV(6, float, 32, 8, 6, 192, 64, 8, 8, 3);
-    MI_BS_LIST(float, 32);
-    MI_BS(float, 32, 4, 512, 64, 8, 8, 8);
-    MI_BS(float, 32, 1, 1024, 128, 8, 8, 16);  // 3.98 ns per row against 4.25 for 16 x 16 x 4 on one wave
+    // The other Complex<float> Bluestein bodies live in kernels_bs_f32.hip / kernels_bs57_f32.hip, which are compiled WITHOUT the SLP
+    // vectoriser (+1 ... +9.5 % per inner length, profiles/r4/ab_noslp_primes_f32.jsonl); these two inner lengths lose without it
+    // (2048: -4.8 %, 1792: -2.6 %) and stay in this unit.
     MI_BS(float, 32, 1, 2048, 128, 8, 16, 16);  // 8.84 against 9.57 for 16 x 16 x 8
-    MI_BS(float, 32, 1, 8192, 512, 16, 16, 32);  // 1.22 TB/s against 0.97 for 16 x 8 x 8 x 8 (one exchange fewer)
-    MI_BS_LIST3_F32(float, 32);
+    MI_BS(float, 32, 1, 1792, 128, 16, 16, 7);
     // tuning: the orders / thread counts the defaults were measured against, and the large inner lengths without the split exchange
     MI_BSV(1, float, 32, 2, 512, 64, 8, 8, 8);
     MI_BSV(1, float, 32, 1, 1024, 64, 16, 16, 4);

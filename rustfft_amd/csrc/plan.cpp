@@ -36,6 +36,7 @@ void ensure_registry() {
         register_k2f_f32(r);
         register_k2f_f64(r);
         register_np2_f32(r);
+        register_bs_f32(r);
 #if defined(MI355_MINIMAL)
         register_bs57_f32(r);
         register_np2_f64(r);
@@ -45,6 +46,8 @@ void ensure_registry() {
         register_rader_f32_1(r);
         register_rader_f32_2(r);
         register_rader_f32_3(r);
+        register_rader_f32_ns0(r);
+        register_rader_f32_ns1(r);
         register_rader_f64_0(r);
         register_rader_f64_1(r);
         register_rader_f64_2(r);
@@ -133,6 +136,8 @@ void ensure_registry() {
         register_rader_f32_1(r);
         register_rader_f32_2(r);
         register_rader_f32_3(r);
+        register_rader_f32_ns0(r);
+        register_rader_f32_ns1(r);
         register_rader_f64_0(r);
         register_rader_f64_1(r);
         register_rader_f64_2(r);

@@ -54,6 +54,7 @@ void register_k2f_f64(std::vector<KernelEntry>&);
 void register_np2_f32(std::vector<KernelEntry>&);  // non-power-of-two: mixed radix, Rader, Bluestein
 void register_np2_f64(std::vector<KernelEntry>&);
 void register_bs57_f32(std::vector<KernelEntry>&);  // Bluestein bodies over 5 * 2^k and 7 * 2^k
+void register_bs_f32(std::vector<KernelEntry>&);    // Complex<float> Bluestein bodies over 2^k and 3 * 2^k (compiled without the SLP vectoriser)
 void register_bs57_f64(std::vector<KernelEntry>&);
 // generated: large-N pass kernels for 7-smooth tile heights (tools/gen_k2g_kernels.py)
 void register_k2g_f32_0(std::vector<KernelEntry>&);
@@ -138,6 +139,8 @@ void register_rader_f32_0(std::vector<KernelEntry>&);
 void register_rader_f32_1(std::vector<KernelEntry>&);
 void register_rader_f32_2(std::vector<KernelEntry>&);
 void register_rader_f32_3(std::vector<KernelEntry>&);
+void register_rader_f32_ns0(std::vector<KernelEntry>&);  // the Complex<float> bodies compiled without the SLP vectoriser (tools/gen_rader_kernels.py NOSLP_F32)
+void register_rader_f32_ns1(std::vector<KernelEntry>&);
 void register_rader_f64_0(std::vector<KernelEntry>&);
 void register_rader_f64_1(std::vector<KernelEntry>&);
 void register_rader_f64_2(std::vector<KernelEntry>&);

@@ -18,12 +18,20 @@ def test_rader_lists_match_the_generator():
     for tag, ty, prec in (("f32", "float", 32), ("f64", "double", 64)):
         primes = sorted(primes13 + [p for (pr, p) in gen.EXTRA31 if pr == prec])
         have = {}
-        for ci in range(gen.NFILES):
-            text = open(os.path.join(ROOT, "rustfft_amd", "csrc", f"kernels_rader_{tag}_{ci}.hip")).read()
+        units = [str(ci) for ci in range(gen.NFILES)] + ([f"ns{ci}" for ci in range(gen.NS_FILES)] if prec == 32 else [])
+        for unit in units:
+            text = open(os.path.join(ROOT, "rustfft_amd", "csrc", f"kernels_rader_{tag}_{unit}.hip")).read()
             for m in re.finditer(r"MI_RADER\((\w+), (\d+), (\d+), (\d+), ([\d, ]+)\);\s*// p = (\d+)", text):
                 assert m.group(1) == ty and int(m.group(2)) == prec
+                assert int(m.group(6)) not in have, "a prime has one body"
                 have[int(m.group(6))] = (int(m.group(3)), int(m.group(4)), [int(v) for v in m.group(5).split(",")])
+                # the bodies measured faster without the SLP vectoriser sit in the units the Makefile compiles with -fno-slp-vectorize
+                assert (prec == 32 and int(m.group(6)) in gen.NOSLP_F32) == unit.startswith("ns"), (tag, unit, m.group(6))
         assert sorted(have) == primes, (tag, sorted(set(primes) ^ set(have)))
+        mk = open(os.path.join(ROOT, "rustfft_amd", "csrc", "Makefile")).read()
+        for unit in units:
+            assert f"kernels_rader_{tag}_{unit}.o" in mk, unit
+            assert (f"kernels_rader_{tag}_{unit}" in mk.split("NOSLP :=")[1].split("\n")[0]) == unit.startswith("ns")
         for p in primes:
             f, mode, rad, tpf = gen.choose(p, prec)
             if mode == 1 and (prec, p) in gen.MODE5 and len(rad) >= 2:

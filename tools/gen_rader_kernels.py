@@ -160,28 +160,40 @@ MODE5 = ({(32, p) for p in (37, 41, 43, 53, 67, 71, 101, 109, 127, 131, 137, 151
          {(64, p) for p in (41, 43, 53, 71, 113, 127, 131, 193, 197, 211, 251, 331, 337, 379, 397, 463, 487, 491, 521, 541, 547, 631, 641, 701, 751, 769, 911, 1249, 1321, 1601, 1621, 1801, 1951, 2003, 2113, 2251, 2281, 2311, 2377, 2549, 2647, 2689, 2731, 2801, 2861, 2917, 2971, 3001, 3121, 3169, 3251, 3329, 3389, 3529, 3631, 3697, 3851, 4001)})
 
 
+# Complex<f32> bodies that run >= 3 % faster compiled WITHOUT the SLP vectoriser (one-process A/B of two builds over every prime,
+# profiles/r4/ab_noslp_primes_f32.jsonl: +3 ... +29 %, mostly radix-11 rows loops; the 256-VGPR rows loops lose 12 - 21 % without it and
+# the family median is -1 %): they go into their own translation units, which the Makefile compiles with -fno-slp-vectorize.
+NOSLP_F32 = {89, 353, 463, 617, 631, 661, 673, 701, 727, 757, 859, 881, 991, 2029, 2143, 2179, 2269, 2647, 2801, 2857, 3511, 3851, 4057}
+NS_FILES = 2
+
+
 def main():
     s13 = set(g.smooth(4096, [2, 3, 5, 7, 11, 13]))
     primes13 = [p for p in range(17, 4097) if is_prime(p) and (p - 1) in s13 and p not in SKIP]
     for tag, ty, prec in (("f32", "float", 32), ("f64", "double", 64)):
         modes = {}
         primes = sorted(primes13 + [p for (pr, p) in EXTRA31 if pr == prec])
-        for ci in range(NFILES):
+        noslp = [p for p in primes if prec == 32 and p in NOSLP_F32]
+        primes = [p for p in primes if p not in noslp]
+        units = [(str(ci), primes[ci::NFILES], "") for ci in range(NFILES)]
+        if noslp:
+            units += [(f"ns{ci}", noslp[ci::NS_FILES], " (the bodies that win without the SLP vectoriser: compiled with -fno-slp-vectorize)") for ci in range(NS_FILES)]
+        for name, plist, note in units:
             lines = []
-            for p in primes[ci::NFILES]:
+            for p in plist:
                 f, mode, rad, tpf = choose(p, prec)
                 if mode == 1 and (ALT5 or (prec, p) in MODE5) and len(rad) >= 2:
                     mode = 5
                 modes[mode] = modes.get(mode, 0) + 1
                 lines.append(f"    MI_RADER({ty}, {prec}, {f}, {mode}, {p - 1}, {tpf}, {', '.join(map(str, rad))});  // p = {p}")
-            path = os.path.join(ROOT, "rustfft_amd", "csrc", f"kernels_rader_{tag}_{ci}.hip")
+            path = os.path.join(ROOT, "rustfft_amd", "csrc", f"kernels_rader_{tag}_{name}.hip")
             with open(path, "w") as fh:
                 fh.write(f"// GENERATED by tools/gen_rader_kernels.py — do not edit.  Compiled Rader bodies for the primes <= 4096 whose p - 1 is\n"
-                         f"// 13-smooth, and the few with a factor 17 .. 31 that beat Bluestein (part {ci + 1} of {NFILES}), Complex<{ty}>.\n"
+                         f"// 13-smooth, and the few with a factor 17 .. 31 that beat Bluestein (unit {name}){note}, Complex<{ty}>.\n"
                          + ("#define MI355_PK_CMUL 1\n" if prec == 32 else "") +
                          '#include "launch.h"\nnamespace mi355 {\n'
-                         f"void register_rader_{tag}_{ci}(std::vector<KernelEntry>& reg) {{\n" + "\n".join(lines) + "\n}\n}  // namespace mi355\n")
-        print(tag, len(primes), "primes; bodies by mode:", modes)
+                         f"void register_rader_{tag}_{name}(std::vector<KernelEntry>& reg) {{\n" + "\n".join(lines) + "\n}\n}  // namespace mi355\n")
+        print(tag, len(primes) + len(noslp), "primes; bodies by mode:", modes)
 
 
 if __name__ == "__main__":
