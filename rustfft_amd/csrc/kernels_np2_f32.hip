@@ -23,12 +23,22 @@ void register_np2_f32(std::vector<KernelEntry>& reg) {
     // rader_rows_body).  Measured on MI355X (2 GiB of rows): 3.0 TB/s, against 2.3 (one row per workgroup, staged rows,
     // variant 1), 2.1 (variant 2: scatter on load, 128 threads) and 2.4 (variant 4: no prefetch of the next row).
     // (round 2, interleaved A/B of seven schedules of 1008: 14 x 9 x 8 on 126 threads = two full waves: 3.36 TB/s against 3.22)
-    MI_RADER(float, 32, 8, 2, 1008, 126, 14, 9, 8);
+    // (the PRODUCTION body of 1009 is generated now -- kernels_rader_f32_ns*.hip, tools/gen_rader_kernels.py FORCE: the rows loop without
+    // the next-row prefetch at four waves per SIMD, compiled without the SLP vectoriser; the round-1 .. 3 body is tuning variant 72)
+    MI_RADERV(72, float, 32, 8, 2, 1008, 126, 14, 9, 8);
     MI_RADERV(37, float, 32, 8, 2, 1008, 144, 16, 9, 7);
     MI_RADERV(1, float, 32, 1, 0, 1008, 144, 16, 9, 7);
     MI_RADERV(2, float, 32, 1, 1, 1008, 128, 16, 9, 7);
     MI_RADERV(3, float, 32, 32, 2, 1008, 144, 16, 9, 7);
     MI_RADERV(4, float, 32, 8, 3, 1008, 144, 16, 9, 7);
+    MI_RADERV(64, float, 32, 8, 3, 1008, 126, 14, 9, 8);  // the production schedule without the next-row prefetch: four waves per SIMD
+    MI_RADERV(65, float, 32, 16, 3, 1008, 126, 14, 9, 8);
+    MI_RADERV(66, float, 32, 8, 3, 1008, 126, 8, 9, 14);
+    MI_RADERV(67, float, 32, 8, 3, 1008, 112, 16, 9, 7);
+    MI_RADERV(68, float, 32, 8, 3, 1008, 126, 16, 9, 7);
+    MI_RADERV(69, float, 32, 8, 3, 1008, 84, 12, 12, 7);
+    MI_RADERV(70, float, 32, 4, 3, 1008, 126, 14, 9, 8);
+    MI_RADERV(71, float, 32, 32, 3, 1008, 126, 14, 9, 8);
     // tuning: other schedules of the inner length 1008 = 2^4 3^2 7 in the rows loop
     MI_RADERV(30, float, 32, 8, 2, 1008, 126, 8, 9, 14);
     MI_RADERV(31, float, 32, 8, 2, 1008, 126, 14, 9, 8);

@@ -12,11 +12,11 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 def test_rader_lists_match_the_generator():
     import gen_rader_kernels as gen
 
-    assert not (gen.ALT or gen.ALT2 or gen.ALT3 or gen.ALT5), "RADER_ALT must not be set while testing"
+    assert not (gen.ALT or gen.ALT2 or gen.ALT3 or gen.ALT5 or gen.ALT6), "RADER_ALT must not be set while testing"
     s13 = set(gen.g.smooth(4096, [2, 3, 5, 7, 11, 13]))
-    primes13 = [p for p in range(17, 4097) if gen.is_prime(p) and (p - 1) in s13 and p not in gen.SKIP]
+    primes13 = [p for p in range(17, 4097) if gen.is_prime(p) and (p - 1) in s13]
     for tag, ty, prec in (("f32", "float", 32), ("f64", "double", 64)):
-        primes = sorted(primes13 + [p for (pr, p) in gen.EXTRA31 if pr == prec])
+        primes = sorted([p for p in primes13 if (prec, p) not in gen.SKIP] + [p for (pr, p) in gen.EXTRA31 if pr == prec])
         have = {}
         units = [str(ci) for ci in range(gen.NFILES)] + ([f"ns{ci}" for ci in range(gen.NS_FILES)] if prec == 32 else [])
         for unit in units:
@@ -26,7 +26,7 @@ def test_rader_lists_match_the_generator():
                 assert int(m.group(6)) not in have, "a prime has one body"
                 have[int(m.group(6))] = (int(m.group(3)), int(m.group(4)), [int(v) for v in m.group(5).split(",")])
                 # the bodies measured faster without the SLP vectoriser sit in the units the Makefile compiles with -fno-slp-vectorize
-                assert (prec == 32 and int(m.group(6)) in gen.NOSLP_F32) == unit.startswith("ns"), (tag, unit, m.group(6))
+                assert (prec == 32 and (int(m.group(6)) in gen.NOSLP_F32 or int(m.group(6)) in gen.MODE3_F32)) == unit.startswith("ns"), (tag, unit, m.group(6))
         assert sorted(have) == primes, (tag, sorted(set(primes) ^ set(have)))
         mk = open(os.path.join(ROOT, "rustfft_amd", "csrc", "Makefile")).read()
         for unit in units:
@@ -36,6 +36,8 @@ def test_rader_lists_match_the_generator():
             f, mode, rad, tpf = gen.choose(p, prec)
             if mode == 1 and (prec, p) in gen.MODE5 and len(rad) >= 2:
                 mode = 5
+            if prec == 32 and p in gen.MODE3_F32 and mode in (2, 4):
+                mode = 3
             assert have[p] == (f, mode, [p - 1, tpf] + list(rad)), (tag, p, have[p], (f, mode, rad, tpf))
     # the measured lists only name primes that have a body, and a prime is in one list of a kind at most
     for prec in (32, 64):

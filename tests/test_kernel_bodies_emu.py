@@ -440,15 +440,17 @@ def test_compiled_rader_bodies_every_form(emu_planner, oracle, dtype):
     planner = emu_planner(dtype)
     f32 = dtype == np.complex64
     prec = 32 if f32 else 64
-    primes = ([97, 127, 193, 257, 271, 449, 541, 769, 811, 1201, 727, 883, 1297, 2003, 2081, 4051, 4057, 137, 647, 683, 2143] if f32 else
+    primes = ([97, 127, 193, 257, 271, 449, 541, 769, 811, 1009, 1201, 727, 883, 1297, 2003, 2081, 4051, 4057, 137, 647, 683, 2143] if f32 else
               [97, 127, 193, 257, 541, 727, 811, 883, 937, 1409, 911, 1201, 1297, 2081, 2801, 3697, 4057, 613, 2053, 3911])  # (the last ones: p - 1 has a factor 17 .. 31)
 
     def form(p):
         mode = gen.choose(p, prec)[1]
+        if f32 and p in gen.MODE3_F32 and mode in (2, 4):
+            return "m3"  # the Complex<f32> rows loops that measured faster without the prefetch (and without the SLP vectoriser)
         return "m5" if mode == 1 and (prec, p) in gen.MODE5 else "m%d" % mode
 
     want = {p: form(p) for p in primes}
-    assert {"m1", "m2", "m4", "m5"} <= set(want.values()) if f32 else {"m1", "m3", "m5"} <= set(want.values()), want
+    assert {"m1", "m2", "m3", "m4", "m5"} <= set(want.values()) if f32 else {"m1", "m3", "m5"} <= set(want.values()), want
     for p, form in want.items():
         for d in (0, 1):
             fft = planner.plan_fft(p, d)

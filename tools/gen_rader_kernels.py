@@ -29,7 +29,11 @@ F64_ROWS = {727, 811, 991, 1201, 1297, 1373, 1621, 1783, 1801, 1951, 2081, 2251,
 WIDE_ROWS = ({(32, p) for p in (193, 257, 271, 281, 331, 337, 353, 397, 401, 421, 433, 449, 463, 487, 491, 541, 577, 601, 617, 631, 641,
                                 661, 673, 769)} |
              {(64, p) for p in (193, 211, 241, 257, 281, 331, 337, 397, 401, 421, 433, 449, 463, 487, 491, 541, 577, 601, 641, 769)})
-SKIP = {1009}  # hand-tuned instantiation in kernels_np2_*.hip
+SKIP = {(64, 1009)}  # (prec, p): hand-tuned instantiation in kernels_np2_f64.hip
+# config 4's prime, Complex<f32>: the rows loop WITHOUT the next-row prefetch (MODE 3, 124 VGPRs: four waves per SIMD) compiled without the
+# SLP vectoriser: 4.85 -> 4.35 ms for 2^19 rows (+11 %; with the vectoriser MODE 3 spills at the 128-VGPR cap: 5.88;
+# profiles/r4/ab_c4_noslp_variants.jsonl, ab_c4_mode3_variants.jsonl: 16 or 32 rows per workgroup the same, other schedules spill)
+FORCE = {(32, 1009): (8, 3, [14, 9, 8], 126)}
 
 
 def is_prime(n):
@@ -103,6 +107,9 @@ ALT3 = os.environ.get("RADER_ALT") == "3"  # experiment 3 (round 3, after the ba
 
 def choose(p, prec):
     n = p - 1
+    if (prec, p) in FORCE:
+        f, mode, rad, tpf = FORCE[(prec, p)]
+        return (f, mode, list(rad), tpf)
     if (ALT3 or (prec, p) in MODE1_BACK) and (prec, p) not in EXTRA31:
         rad, tpf = g.schedule(n)
         pitch, xs, emax, twreg = layout(n, rad, tpf)
@@ -152,6 +159,11 @@ def choose(p, prec):
     return (f, 0, rad, tpf)
 
 
+# Complex<f32> rows loops that run 3 - 14 % faster WITHOUT the next-row prefetch (MODE 3: 128-VGPR cap, four waves per SIMD) once they are
+# compiled without the SLP vectoriser (RADER_ALT=6 build against the shipped choice, every Rader prime in one process,
+# profiles/r4/rader_mode3_noslp_ab_f32.jsonl: the other 60 rows loops spill at that cap and lose, median -30 %)
+MODE3_F32 = {401, 421, 433, 487, 541, 601, 641, 769, 811, 881, 883, 991, 1297}
+ALT6 = os.environ.get("RADER_ALT") == "6"  # experiment 6 (round 4): every Complex<f32> rows loop (MODE 2 / 4) as MODE 3 in the no-SLP units
 ALT5 = os.environ.get("RADER_ALT") == "5"  # experiment 5: every side-by-side body with the register hand-over (MODE 5)
 # (prec, p) -> MODE 5 instead of MODE 1 where the hand-over measured > 4 % faster in a one-process A/B of every side-by-side body
 # (RADER_ALT=5 build; profiles/r3/rader_mode5_ab_*.jsonl: f32 median +3.5 %, -36 .. +22 %; f64 median +2.5 %, -33 .. +50 %; a second
@@ -163,17 +175,18 @@ MODE5 = ({(32, p) for p in (37, 41, 43, 53, 67, 71, 101, 109, 127, 131, 137, 151
 # Complex<f32> bodies that run >= 3 % faster compiled WITHOUT the SLP vectoriser (one-process A/B of two builds over every prime,
 # profiles/r4/ab_noslp_primes_f32.jsonl: +3 ... +29 %, mostly radix-11 rows loops; the 256-VGPR rows loops lose 12 - 21 % without it and
 # the family median is -1 %): they go into their own translation units, which the Makefile compiles with -fno-slp-vectorize.
-NOSLP_F32 = {89, 353, 463, 617, 631, 661, 673, 701, 727, 757, 859, 881, 991, 2029, 2143, 2179, 2269, 2647, 2801, 2857, 3511, 3851, 4057}
+NOSLP_F32 = {1009, 89, 353, 463, 617, 631, 661, 673, 701, 727, 757, 859, 881, 991, 2029, 2143, 2179, 2269, 2647, 2801, 2857, 3511, 3851, 4057}
 NS_FILES = 2
 
 
 def main():
     s13 = set(g.smooth(4096, [2, 3, 5, 7, 11, 13]))
-    primes13 = [p for p in range(17, 4097) if is_prime(p) and (p - 1) in s13 and p not in SKIP]
+    primes13 = [p for p in range(17, 4097) if is_prime(p) and (p - 1) in s13]
     for tag, ty, prec in (("f32", "float", 32), ("f64", "double", 64)):
         modes = {}
-        primes = sorted(primes13 + [p for (pr, p) in EXTRA31 if pr == prec])
-        noslp = [p for p in primes if prec == 32 and p in NOSLP_F32]
+        primes = sorted([p for p in primes13 if (prec, p) not in SKIP] + [p for (pr, p) in EXTRA31 if pr == prec])
+        alt6 = {p for p in primes if (ALT6 or p in MODE3_F32) and prec == 32 and choose(p, prec)[1] in (2, 4)}
+        noslp = [p for p in primes if prec == 32 and (p in NOSLP_F32 or p in alt6)]
         primes = [p for p in primes if p not in noslp]
         units = [(str(ci), primes[ci::NFILES], "") for ci in range(NFILES)]
         if noslp:
@@ -184,6 +197,8 @@ def main():
                 f, mode, rad, tpf = choose(p, prec)
                 if mode == 1 and (ALT5 or (prec, p) in MODE5) and len(rad) >= 2:
                     mode = 5
+                if p in alt6:
+                    mode = 3
                 modes[mode] = modes.get(mode, 0) + 1
                 lines.append(f"    MI_RADER({ty}, {prec}, {f}, {mode}, {p - 1}, {tpf}, {', '.join(map(str, rad))});  // p = {p}")
             path = os.path.join(ROOT, "rustfft_amd", "csrc", f"kernels_rader_{tag}_{name}.hip")
