@@ -26,6 +26,9 @@ void register_np2_f32(std::vector<KernelEntry>& reg) {
     // (the PRODUCTION body of 1009 is generated now -- kernels_rader_f32_ns*.hip, tools/gen_rader_kernels.py FORCE: the rows loop without
     // the next-row prefetch at four waves per SIMD, compiled without the SLP vectoriser; the round-1 .. 3 body is tuning variant 72)
     MI_RADERV(72, float, 32, 8, 2, 1008, 126, 14, 9, 8);
+#if defined(MI355_MINIMAL) && !defined(MI355_MINIMAL_RADER)
+    MI_RADER(float, 32, 8, 3, 1008, 126, 14, 9, 8);  // `make tuning-min` carries no generated Rader unit: a default body, so that MI355FFT_VARIANT finds the prime
+#endif
     MI_RADERV(37, float, 32, 8, 2, 1008, 144, 16, 9, 7);
     MI_RADERV(1, float, 32, 1, 0, 1008, 144, 16, 9, 7);
     MI_RADERV(2, float, 32, 1, 1, 1008, 128, 16, 9, 7);
