@@ -134,6 +134,18 @@ void register_smooth3_f64_4(std::vector<KernelEntry>&);
 void register_smooth3_f64_5(std::vector<KernelEntry>&);
 void register_smooth3_f64_6(std::vector<KernelEntry>&);
 void register_smooth3_f64_7(std::vector<KernelEntry>&);
+// generated: the Complex<float> schedules that measured faster without the SLP vectoriser (tools/smooth_noslp_choice.json; Makefile NOSLP)
+void register_smooth_f32_ns0(std::vector<KernelEntry>&);
+void register_smooth2_f32_ns0(std::vector<KernelEntry>&);
+void register_smooth2_f32_ns1(std::vector<KernelEntry>&);
+void register_smooth2_f32_ns2(std::vector<KernelEntry>&);
+void register_smooth3_f32_ns0(std::vector<KernelEntry>&);
+void register_smooth3_f32_ns1(std::vector<KernelEntry>&);
+void register_smooth3_f32_ns2(std::vector<KernelEntry>&);
+void register_smooth3_f32_ns3(std::vector<KernelEntry>&);
+void register_smooth3_f32_ns4(std::vector<KernelEntry>&);
+void register_smooth3_f32_ns5(std::vector<KernelEntry>&);
+void register_smooth3_f32_ns6(std::vector<KernelEntry>&);
 // generated: compiled Rader bodies for the primes <= 4096 with 13-smooth p - 1 (tools/gen_rader_kernels.py)
 void register_rader_f32_0(std::vector<KernelEntry>&);
 void register_rader_f32_1(std::vector<KernelEntry>&);

@@ -44,3 +44,39 @@ def test_rader_lists_match_the_generator():
         for name in ("MODE1_BACK", "MODE5"):
             for (pr, p) in getattr(gen, name):
                 assert gen.is_prime(p) and 17 <= p <= 4096, (name, p)
+
+
+def test_smooth_units_match_the_generator_and_the_noslp_choice():
+    """The compiled single-kernel schedules (tools/gen_smooth_kernels.py): every length sits in exactly one unit, the Complex<f32> lengths
+    of tools/smooth_noslp_choice.json (measured faster without the SLP vectoriser) in the "ns" units and nowhere else, and the Makefile
+    compiles exactly those units with -fno-slp-vectorize."""
+    import json
+
+    import gen_smooth_kernels as gs
+
+    choice = json.load(open(os.path.join(ROOT, "tools", "smooth_noslp_choice.json")))
+    mk = open(os.path.join(ROOT, "rustfft_amd", "csrc", "Makefile")).read()
+    noslp_line = mk.split("NOSLP :=")[1].split("\n")[0].split()
+    s13 = set(gs.smooth(4096, [2, 3, 5, 7, 11, 13]))
+    want = {
+        "smooth": [x for x in gs.smooth(4096, [2, 3, 5, 7, 11, 13]) if x > 2 and (x & (x - 1)) and x != 1200],
+        "smooth3": [x for x in gs.smooth(4096, [2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31]) if x not in s13],
+        "smooth2": ([x for x in gs.smooth(16384, [2, 3, 5, 7]) if x > 4096 and (x & (x - 1)) and gs.big_schedule(x, (16, 32))] +
+                    [x for x in gs.smooth(32768, [2, 3, 5, 7]) if x > 16384 and (x & (x - 1)) and gs.big_schedule32(x)]),
+    }
+    csrc = os.path.join(ROOT, "rustfft_amd", "csrc")
+    for fam, sizes in want.items():
+        seen = {}
+        for fn in sorted(os.listdir(csrc)):
+            m = re.fullmatch(rf"kernels_{fam}_f32_(\w+)\.hip", fn)
+            if not m:
+                continue
+            unit = m.group(1)
+            assert f"kernels_{fam}_f32_{unit}.o" in mk and (f"kernels_{fam}_f32_{unit}" in noslp_line) == unit.startswith("ns"), (fam, unit)
+            for km in re.finditer(r"MI_K1X?\(float, 32, \d+, (?:true|false), (?:\d+, \"\w*\", )?(\d+),", open(os.path.join(csrc, fn)).read()):
+                n = int(km.group(1))
+                assert n not in seen, (fam, n)
+                seen[n] = unit
+        assert sorted(seen) == sorted(sizes), (fam, sorted(set(seen) ^ set(sizes))[:10])
+        ns = {n for n, u in seen.items() if u.startswith("ns")}
+        assert ns == set(choice[fam]) & set(sizes), (fam, sorted(ns ^ (set(choice[fam]) & set(sizes)))[:10])

@@ -184,6 +184,24 @@ def big_schedule(n, emaxes=(16, 32)):
     return None
 
 
+# Complex<f32> lengths whose kernel runs >= 2 % faster in BOTH of two one-process A/B runs when compiled WITHOUT the SLP vectoriser
+# (profiles/r4/ab_noslp_{smooth,smooth3,smooth2}_f32_rep{1,2}.jsonl: the vectoriser pairs re / im parts of different values into packed
+# operations and pays in register moves -- 62 of 476 13-smooth lengths, 280 of 563 prime-radix lengths, 147 of 223 large 7-smooth ones, median
+# gain 5 / 8 / 10 %, up to 76 %).  They go into their own translation units ("ns"), which the Makefile compiles with -fno-slp-vectorize.
+_NOSLP = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "smooth_noslp_choice.json")))
+NS_UNITS = {"smooth": 1, "smooth2": 3, "smooth3": 7}
+
+
+def units_of(family, tag, sizes, nfiles):
+    """[(unit name, lengths)]: the numbered units hold what stays with the vectoriser, the "ns" units (Complex<f32> only) the rest."""
+    ns = sorted(set(_NOSLP[family]) & set(sizes)) if tag == "f32" else []
+    keep = [x for x in sizes if x not in set(ns)]
+    out = [(str(ci), keep[ci::nfiles]) for ci in range(nfiles)]
+    if ns:
+        out += [(f"ns{ci}", ns[ci::NS_UNITS[family]]) for ci in range(NS_UNITS[family])]
+    return out
+
+
 def main_big():
     """kernels_smooth2_*: 7-smooth lengths in (4096, 16384] as single split-exchange kernels (one HBM pass instead of two)."""
     nfiles = 4
@@ -192,15 +210,15 @@ def main_big():
         sizes = [x for x in smooth(16384, [2, 3, 5, 7]) if x > 4096 and (x & (x - 1)) and big_schedule(x, emaxes)]
         if prec == 32:  # f32 rows up to 32768 points still fit one workgroup's LDS through the split exchange (<= 132 KB)
             sizes += [x for x in smooth(32768, [2, 3, 5, 7]) if x > 16384 and (x & (x - 1)) and big_schedule32(x)]
-        for ci in range(nfiles):
+        for ci, chunk in units_of("smooth2", tag, sizes, nfiles):
             lines = []
-            for n in sizes[ci::nfiles]:
+            for n in chunk:
                 rad, tpf = big_schedule(n, emaxes) if n <= 16384 else big_schedule32(n)
                 lines.append(k1_line(ty, prec, 1, "true", n, tpf, rad))
             path = os.path.join(ROOT, "rustfft_amd", "csrc", f"kernels_smooth2_{tag}_{ci}.hip")
             with open(path, "w") as fh:
                 fh.write(f"// GENERATED by tools/gen_smooth_kernels.py — do not edit.  Single-kernel schedules (split exchange) for the 7-smooth\n"
-                         f"// lengths in (4096, 16384] (part {ci + 1} of {nfiles}), Complex<{ty}>.\n"
+                         f"// lengths in (4096, 16384] (unit {ci}), Complex<{ty}>.\n"
                          '#include "launch.h"\nnamespace mi355 {\n'
                          f"void register_smooth2_{tag}_{ci}(std::vector<KernelEntry>& reg) {{\n" + "\n".join(lines) + "\n}\n}  // namespace mi355\n")
         print(len(sizes), "lengths in (4096, 16384] (f32: 32768],", tag)
@@ -228,9 +246,9 @@ def main_primes(limits=(("f32", "float", 32, 8, 4096, 14), ("f64", "double", 64,
     for tag, ty, prec, esz, limit, nfiles in limits:
         s13 = set(smooth(limit, [2, 3, 5, 7, 11, 13]))
         sizes = [x for x in smooth(limit, [2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31]) if x not in s13]
-        for ci in range(nfiles):
+        for ci, chunk in units_of("smooth3", tag, sizes, nfiles):
             lines = []
-            for n in sizes[ci::nfiles]:
+            for n in chunk:
                 rad, tpf = schedule31(n)
                 f = max(1, min(ROWS31_TARGET // tpf, (48 * 1024) // ((n + n // 8 + 2) * esz)))  # <= 256 threads: the prime butterflies want > 128 VGPRs
                 # half the rows where a one-process interleaved A/B of every length measured > 4 % (profiles/r2/prime_radix_rows_ab_*.jsonl:
@@ -241,7 +259,7 @@ def main_primes(limits=(("f32", "float", 32, 8, 4096, 14), ("f64", "double", 64,
             path = os.path.join(ROOT, "rustfft_amd", "csrc", f"kernels_smooth3_{tag}_{ci}.hip")
             with open(path, "w") as fh:
                 fh.write(f"// GENERATED by tools/gen_smooth_kernels.py — do not edit.  Compiled K1 schedules for the lengths <= {limit} with a prime\n"
-                         f"// factor 17 .. 31 (in-register prime butterflies; part {ci + 1} of {nfiles}), Complex<{ty}>.\n"
+                         f"// factor 17 .. 31 (in-register prime butterflies; unit {ci}), Complex<{ty}>.\n"
                          '#include "launch.h"\nnamespace mi355 {\n'
                          f"void register_smooth3_{tag}_{ci}(std::vector<KernelEntry>& reg) {{\n" + "\n".join(lines) + "\n}\n}  // namespace mi355\n")
         print(len(sizes), "lengths with a factor 17 .. 31, <=", limit, tag)
@@ -252,8 +270,7 @@ def main():
     main_primes()
     sizes = [x for x in smooth(4096, [2, 3, 5, 7, 11, 13]) if x > 2 and (x & (x - 1)) and x != 1200]
     for tag, ty, prec, esz in (("f32", "float", 32, 8), ("f64", "double", 64, 16)):
-        chunks = [sizes[i::NFILES] for i in range(NFILES)]
-        for ci, chunk in enumerate(chunks):
+        for ci, chunk in units_of("smooth", tag, sizes, NFILES):
             lines = []
             for n in chunk:
                 rad, tpf = schedule(n)
@@ -264,7 +281,7 @@ def main():
             path = os.path.join(ROOT, "rustfft_amd", "csrc", f"kernels_smooth_{tag}_{ci}.hip")
             with open(path, "w") as fh:
                 fh.write(f"// GENERATED by tools/gen_smooth_kernels.py — do not edit.  Compiled K1 schedules for the 13-smooth lengths in\n"
-                         f"// (16, 4096] (part {ci + 1} of {NFILES}), Complex<{ty}>.\n"
+                         f"// (16, 4096] (unit {ci}), Complex<{ty}>.\n"
                          '#include "launch.h"\nnamespace mi355 {\n'
                          f"void register_smooth_{tag}_{ci}(std::vector<KernelEntry>& reg) {{\n" + "\n".join(lines) + "\n}\n}  // namespace mi355\n")
     print(len(sizes), "lengths per precision")
