@@ -68,6 +68,10 @@ void ensure_registry() {
         register_k2g_f32_5(r);
         register_k2g_f32_6(r);
         register_k2g_f32_7(r);
+        register_k2g_f32_ns0(r);
+        register_k2g_f32_ns1(r);
+        register_k2g_f32_ns2(r);
+        register_k2g_f32_ns3(r);
         register_k2g_f64_0(r);
         register_k2g_f64_1(r);
         register_k2g_f64_2(r);

@@ -65,6 +65,10 @@ void register_k2g_f32_4(std::vector<KernelEntry>&);
 void register_k2g_f32_5(std::vector<KernelEntry>&);
 void register_k2g_f32_6(std::vector<KernelEntry>&);
 void register_k2g_f32_7(std::vector<KernelEntry>&);
+void register_k2g_f32_ns0(std::vector<KernelEntry>&);  // the Complex<float> tile heights compiled without the SLP vectoriser (tools/k2g_noslp_choice.json)
+void register_k2g_f32_ns1(std::vector<KernelEntry>&);
+void register_k2g_f32_ns2(std::vector<KernelEntry>&);
+void register_k2g_f32_ns3(std::vector<KernelEntry>&);
 void register_k2g_f64_0(std::vector<KernelEntry>&);
 void register_k2g_f64_1(std::vector<KernelEntry>&);
 void register_k2g_f64_2(std::vector<KernelEntry>&);

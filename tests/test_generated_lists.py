@@ -80,3 +80,30 @@ def test_smooth_units_match_the_generator_and_the_noslp_choice():
         assert sorted(seen) == sorted(sizes), (fam, sorted(set(seen) ^ set(sizes))[:10])
         ns = {n for n, u in seen.items() if u.startswith("ns")}
         assert ns == set(choice[fam]) & set(sizes), (fam, sorted(ns ^ (set(choice[fam]) & set(sizes)))[:10])
+
+
+def test_general_tile_units_match_the_noslp_choice():
+    """tools/gen_k2g_kernels.py: every Complex<f32> tile height sits in exactly one k2g unit, the heights of tools/k2g_noslp_choice.json in
+    the "ns" units (compiled with -fno-slp-vectorize by the Makefile) and nowhere else."""
+    import json
+
+    import gen_k2g_kernels as gk
+
+    choice = set(json.load(open(os.path.join(ROOT, "tools", "k2g_noslp_choice.json")))["f32"])
+    mk = open(os.path.join(ROOT, "rustfft_amd", "csrc", "Makefile")).read()
+    noslp_line = mk.split("NOSLP :=")[1].split("\n")[0].split()
+    csrc = os.path.join(ROOT, "rustfft_amd", "csrc")
+    seen = {}
+    for fn in sorted(os.listdir(csrc)):
+        m = re.fullmatch(r"kernels_k2g_f32_(\w+)\.hip", fn)
+        if not m:
+            continue
+        unit = m.group(1)
+        assert f"kernels_k2g_f32_{unit}.o" in mk and (f"kernels_k2g_f32_{unit}" in noslp_line) == unit.startswith("ns"), unit
+        for km in re.finditer(r"MI_K2GT\(float, 32, \d+, (\d+),", open(os.path.join(csrc, fn)).read()):
+            h = int(km.group(1))
+            assert h not in seen, h
+            seen[h] = unit
+    want = [x for x in gk.g.smooth(640, [2, 3, 5, 7, 11, 13]) if x >= 25]
+    assert sorted(seen) == want
+    assert {h for h, u in seen.items() if u.startswith("ns")} == choice & set(want) == gk.NOSLP_F32 & set(want)

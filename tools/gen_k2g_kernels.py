@@ -45,13 +45,24 @@ def tall_schedule(n, emax, tpfmax, maxp):
     return best[1], best[2]
 
 
+# Complex<f32> tile heights whose first + later kernels, summed over every sampled plan that uses them, run >= 2 % faster in BOTH of two
+# runs when compiled WITHOUT the SLP vectoriser (tools/r4/k2g_kernel_ab.py: per-kernel times of 640 two- and three-pass lengths in two
+# builds, profiles/r4/k2g_kernel_ab_rep{1,2}.jsonl: 89 of 166 heights, +2 ... +36 %, one height loses): their own units ("ns"), which the
+# Makefile compiles with -fno-slp-vectorize.
+import json as _json
+NOSLP_F32 = set(_json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "k2g_noslp_choice.json")))["f32"])
+NS_FILES = 4
+
+
 def main():
     # round 2: heights with the factors 11 and 13 as well, so that EVERY 13-smooth length above one workgroup runs in two to four
     # column-tile passes (before: lengths with 11 or 13 above ~5100 went through the fused Bluestein at 7x the algorithmic traffic)
     rs = [x for x in g.smooth(640, [2, 3, 5, 7, 11, 13]) if x >= 25]
     for tag, ty, prec, esz in (("f32", "float", 32, 8), ("f64", "double", 64, 16)):
-        chunks = [rs[i::NFILES] for i in range(NFILES)]
-        for ci, chunk in enumerate(chunks):
+        keep = [x for x in rs if not (prec == 32 and x in NOSLP_F32)]
+        ns = [x for x in rs if prec == 32 and x in NOSLP_F32]
+        units = [(str(i), keep[i::NFILES]) for i in range(NFILES)] + ([(f"ns{i}", ns[i::NS_FILES]) for i in range(NS_FILES)] if ns else [])
+        for ci, chunk in units:
             lines = []
             for r in chunk:
                 rad, tpf = g.schedule(r)
@@ -70,13 +81,13 @@ def main():
             # f64 only: 8 columns (128-byte segments) x <= 128 threads x 16 values.  The f32 form (16 columns x <= 64 threads x 32
             # values) does not fit 128 VGPRs with the general body (100 - 300 B of spills): measured -14 .. +13 % against three
             # passes of short tiles, so f32 keeps three passes; f64 gains 14 - 26 % (10^6: 5.5 -> 6.9 TFLOP/s).
-            for r in (TALL[ci::NFILES] if prec == 64 else []):
+            for r in (TALL[int(ci)::NFILES] if prec == 64 else []):
                 rad, tpf = tall_schedule(r, 16, 128, 4)
                 lines.append(f"    MI_K2GS({ty}, {prec}, 8, {r}, {tpf}, {', '.join(map(str, rad))});")
             path = os.path.join(ROOT, "rustfft_amd", "csrc", f"kernels_k2g_{tag}_{ci}.hip")
             with open(path, "w") as fh:
                 fh.write(f"// GENERATED by tools/gen_k2g_kernels.py — do not edit.  Large-N pass kernels for the 13-smooth tile heights in\n"
-                         f"// [25, 640] (part {ci + 1} of {NFILES}), Complex<{ty}>.\n"
+                         f"// [25, 640] (unit {ci}), Complex<{ty}>.\n"
                          '#include "launch.h"\nnamespace mi355 {\n'
                          f"void register_k2g_{tag}_{ci}(std::vector<KernelEntry>& reg) {{\n" + "\n".join(lines) + "\n}\n}  // namespace mi355\n")
         # Rader-fused forms of every tile (multi-kernel Rader for primes beyond one workgroup, k2g_body FUSE 4 / 5 / 6): the inner
