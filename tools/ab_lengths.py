@@ -84,6 +84,8 @@ def main():
         tb = [batch * 2 * n * esz / (t * 1e-3) / 1e12 for t in best]
         print(json.dumps({"n": n, "a_TBps": round(tb[0], 3), "b_TBps": round(tb[1], 3), "b_over_a": round(tb[1] / tb[0], 3), "rel_l2_b_vs_a": diff,
                           "plan_a": ffts[0].describe(), "plan_b": ffts[1].describe()}), flush=True)
+        for f in ffts:
+            f.trim_workspaces()  # a planner keeps its plans: hundreds of lengths would otherwise hold hundreds of workspaces
 
 
 if __name__ == "__main__":
