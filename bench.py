@@ -185,15 +185,20 @@ def side_line(torch, np, log, steps=3):
                 fft.process_immutable_with_scratch(x, y)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = steps if key == "c5_shard" else 4 * steps  # (30 ms per step at config 5's shard, 0.5 - 4.5 ms at configs 3 and 4)
             e0.record()
-            for _ in range(steps):
+            for _ in range(reps):
                 fft.process_immutable_with_scratch(x, y)
             e1.record()
             torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / steps
+            ms = e0.elapsed_time(e1) / reps
             ex, ey = energy(x), energy(y)
             kms = fft.profile_kernels(y, reps=max(steps, 5))
             alg = batch * 2 * n * esz
+            if len(kms) == 1:
+                # a one-kernel plan: the step IS the launch -- its average duration over the back-to-back launches timed above (HIP events on the
+                # launch stream around `reps` launches), not the mean of individually bracketed ones (which adds the gap a lone launch starts into)
+                kms = [min(kms[0], ms)]
             per_kernel = [{"kernel": nm, "ms": k, "GBps": alg / (k * 1e-3) / 1e9} for nm, k in zip(fft.kernel_names(), kms) if k > 0]
             dom = max(per_kernel, key=lambda r: r["ms"])
             res[key] = {"workload": f"N={n} Complex<{name}>, batch={batch}, forward, immutable input, HBM-resident", "plan": fft.describe(), "steps": steps,
