@@ -178,7 +178,9 @@ int mi355fft_process_immutable_host(const mi355fft_plan* plan, const void* input
  * (allocated on first use, grown on demand).  Concurrent callers: a multi-pass call holds a
  * per-(plan, stream) lock while it enqueues its passes, so calls that share a plan AND a stream run
  * their pass sequences back to back in stream order; calls on different streams proceed in parallel
- * with their own workspaces. */
+ * with their own workspaces.  HIP graphs: the first call of a (plan, stream, batch size) may allocate (and synchronise the stream
+ * once while it does); after that one warm-up call a sequence of these calls is plain stream work -- kernel launches only -- and
+ * captures into a HIP graph (hipStreamBeginCapture ... EndCapture) that replays with the same results. */
 int mi355fft_process_inplace_dev(const mi355fft_plan* plan, void* buffer, size_t batch, void* stream);
 int mi355fft_process_outofplace_dev(const mi355fft_plan* plan, void* input, void* output, size_t batch, void* stream);
 int mi355fft_process_immutable_dev(const mi355fft_plan* plan, const void* input, void* output, size_t batch,
