@@ -48,6 +48,9 @@ void register_k2f_f32(std::vector<KernelEntry>& reg) {
     // 2^22: the one-pass plan runs its second pass on 16-column tiles of 1024 threads; a fused launch has ONE block size, so
     // the second pass runs here on 8-column tiles of 512 threads (two workgroups per CU, like the first pass)
     MI_K2F(0, float, 32, "k2first<2048, 64, 8, 16, 16>xF8", 8, true, 0, S2048, "k2later<2048, 128, 8, 16, 16>xF16p2", 8, true, 0, S2048);         // 2^22
+    // tuning 23: the 256 x 256 pair (2^16; the fused front of 2^23 / 2^24) on 16-column tiles of 256 threads (the shape the Complex<f64> pair has):
+    // 2^16 5.65 -> 6.50 ms, 2^23 8.88 -> 9.47, 2^24 9.33 -> 10.02 (profiles/r4/ab_fused_f16tiles_2p*.jsonl): slower
+    MI_K2FV(23, float, 32, "k2first<256, 16, 16, 16>xF32", 16, false, 0, S256, "k2later<256, 16, 16, 16>xF32", 16, false, 0, S256);
     // tuning 21: 2^20 with the SECOND pass as two columns per lane (16-byte ring loads and output stores)
     using S1024P = Sched<1024, 64, 8, 8, 16>;
     MI_K2FV(21, float, 32, "k2first<1024, 32, 8, 8, 16>xF16t", 16, true, 128, S1024, "k2later<1024, 32, 8, 8, 16>xF16t", 16, true, 4224, S1024P);
