@@ -17,6 +17,12 @@ void register_bs57_f32(std::vector<KernelEntry>& reg) {
     MI_BS(float, 32, 1, 7168, 512, 16, 16, 28);
     MI_BSS(float, 32, 1, 10240, 640, 10, 8, 8, 16);  // 88.5 against 101.5 for 32 x 20 x 16 on 512 threads
     MI_BSS(float, 32, 1, 14336, 512, 32, 28, 16);
+    // Measured and NOT compiled: the 9 * 2^k and 15 * 2^k inner lengths (576 ... 4608, 960 ... 7680; worst-case padding 1.25x -> 1.17x): every
+    // prime that would move, old ladder against new in one process (profiles/r4/ab_ladder915_f32_rep*.jsonl): 576 -7 %, 960 -17 %, 1152 -8 %,
+    // 2304 -5 %, 3840 -15 %, 4608 -2 %, 1920 +4 %, 7680 +32 % -- and 7680 only beat the old 8192 body, which the lighter 8192 schedule
+    // (kernels_bs_f32.hip) now beats by more: the radix-9 / 15 sub-passes cost more than the padding they save.
+    MI_BSV(4, float, 32, 1, 7168, 512, 14, 8, 8, 8);  // tuning 4 / 5: four lighter sub-passes instead of 16 x 16 x 28
+    MI_BSV(5, float, 32, 1, 7168, 512, 8, 8, 8, 14);
     MI_BSV(1, float, 32, 1, 640, 80, 8, 8, 10);  // tuning: the largest-first order
     MI_BSV(1, float, 32, 1, 1280, 128, 16, 10, 8);  // tuning: the largest-first order
     MI_BSV(1, float, 32, 1, 2560, 256, 16, 16, 10);  // tuning: the largest-first order
@@ -24,5 +30,7 @@ void register_bs57_f32(std::vector<KernelEntry>& reg) {
     MI_BSV(1, float, 32, 1, 896, 112, 8, 8, 14);  // tuning: the largest-first order
     MI_BSV(1, float, 32, 1, 5120, 512, 16, 16, 20);  // tuning: the three-sub-pass schedules
     MI_BSSV(1, float, 32, 1, 10240, 512, 32, 20, 16);
+    MI_BSSV(4, float, 32, 1, 14336, 1024, 14, 16, 8, 8);  // tuning 4 / 5: 14336 in four lighter sub-passes instead of 32 x 28 x 16
+    MI_BSSV(5, float, 32, 1, 14336, 896, 16, 14, 8, 8);
 }
 }  // namespace mi355

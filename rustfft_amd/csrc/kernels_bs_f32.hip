@@ -11,8 +11,13 @@ void register_bs_f32(std::vector<KernelEntry>& reg) {
     MI_BS_LIST(float, 32);
     MI_BS(float, 32, 4, 512, 64, 8, 8, 8);
     MI_BS(float, 32, 1, 1024, 128, 8, 8, 16);  // 3.98 ns per row against 4.25 for 16 x 16 x 4 on one wave
-    MI_BS(float, 32, 1, 8192, 512, 16, 16, 32);  // 1.22 TB/s against 0.97 for 16 x 8 x 8 x 8 (one exchange fewer)
+    // 8192: four lighter sub-passes (16 values per thread, 94 VGPRs, five waves per SIMD).  Rounds 2 - 3 measured 16 x 16 x 32 (132 VGPRs)
+    // ahead, 1.22 against 0.97 TB/s -- with the SLP vectoriser; without it (this unit) the light schedule runs n = 4093 in 2.66 ms against
+    // 3.78: +42 % (profiles/r4/ab_bs8192_variants.jsonl; 16 x 8 x 8 x 8: 2.72).  The old schedule: tuning 6.
+    MI_BS(float, 32, 1, 8192, 512, 8, 8, 8, 16);
+    MI_BSV(6, float, 32, 1, 8192, 512, 16, 16, 32);
     MI_BS_LIST3_F32(float, 32);
+    MI_BSV(5, float, 32, 1, 8192, 512, 16, 8, 8, 8);
     // one-kernel Bluestein for 4096 < n <= 8192 through the split exchange, two-kernel Bluestein for 8192 < n <= 16384 (see kernels_k1_f32.hip
     // for the measurements behind the split)
     MI_BSS(float, 32, 1, 12288, 768, 12, 8, 8, 16);   // four lighter sub-passes: 100.5 ns per row against 115.4 for 32 x 24 x 16 on 512 threads
