@@ -167,8 +167,11 @@ BIG32_WINS = {4375, 4608, 4725, 5103, 5292, 5400, 5760, 5832, 6125, 6300, 7203, 
               15625, 16000}
 
 
+BIG32_OFF = os.environ.get("SMOOTH_BIG32_OFF") == "1"  # experiment: the 16-values-per-thread rule for every length <= 16384
+
+
 def big_schedule(n, emaxes=(16, 32)):
-    if 32 in emaxes and n in BIG32_WINS:
+    if 32 in emaxes and n in BIG32_WINS and not BIG32_OFF:
         r = big_schedule32(n)
         if r:
             return r
