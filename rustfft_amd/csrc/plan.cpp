@@ -1640,9 +1640,6 @@ template <class T> static int execute_fused(Plan& plan, const void* in, void* ou
     const long long grid = k2f_grid((long long)steps, t0, t1, lag);
     if (grid > kMaxGrid) return MI355FFT_ERR_INVALID_ARG;
     if (backend::memset_async(pp.ctrl, 0, cbytes, stream)) return MI355FFT_ERR_HIP;
-#if defined(MI355_EMU)
-    if (getenv("MI355FFT_TRACE_FUSED")) fprintf(stderr, "fused launch: steps %zu units %d t0 %d t1 %d lag %d ns %d grid %lld\n", steps, units, t0, t1, lag, ns, grid);
-#endif
     k.launch(&fp, grid, stream);
     return backend::check_launch() ? MI355FFT_ERR_HIP : MI355FFT_OK;
 }
