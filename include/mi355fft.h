@@ -262,10 +262,21 @@ int mi355fft_measure_copy_ceiling(size_t bytes, double* gbps);
 int mi355fft_plan_set_fused(mi355fft_plan* plan, int mode);
 /* 1 when process_* calls of this plan currently use a fused launch (for a large enough batch), else 0. */
 int mi355fft_plan_is_fused(const mi355fft_plan* plan);
-/* Waits between the workgroups of a fused launch are bounded; a wait that gave up sets an
- * error word instead of hanging the GPU.  This call synchronises `stream` and returns the word of the plan's most recent fused
- * launch on that stream through *error_word (0 = every dependency was met in time; also 0 when the plan never ran fused). */
+/* Waits between the workgroups of a fused launch are bounded; a wait that gave up (the device time-sliced between processes, a debugger
+ * holding a workgroup) raises the plan's STICKY error word for that stream instead of hanging the GPU, and what that launch wrote is invalid.
+ * The word is pinned host memory no launch clears, and the give-up cannot be missed (the reference's contract, src/lib.rs:184: an Fft is
+ * never silently wrong):
+ *   - host slices (mi355fft_process_*_host, mi355fft_multi_process_*_host): the affected rows are transformed again with one launch per
+ *     pass before they are copied back -- the call succeeds with correct results;
+ *   - device buffers: the NEXT mi355fft_process_*_dev / mi355fft_multi_process_*_dev on that plan and stream returns MI355FFT_ERR_HIP without
+ *     running (mi355fft_last_error says why), as do mi355fft_multi_synchronize and mi355fft_plan_destroy; the caller re-runs the failed call
+ *     (mi355fft_plan_set_fused(plan, 0) avoids a repeat).
+ * mi355fft_plan_fused_status synchronises `stream` and returns the word through *error_word (0 = every dependency of every fused launch since
+ * the last report was met in time; also 0 when the plan never ran fused); reporting clears it. */
 int mi355fft_plan_fused_status(const mi355fft_plan* plan, void* stream, unsigned* error_word);
+/* The bound: polls of about half a microsecond before a dependency wait gives up (default 2^21: about a second).  0 makes every wait that is
+ * not already satisfied give up -- how the tests exercise the paths above on a healthy device. */
+int mi355fft_plan_set_fused_wait_limit(mi355fft_plan* plan, int polls);
 /* Workspace placement (off by default).  Identical multi-pass plans run up to 3.6 % apart depending on which device allocation
  * holds their in-place workspace (profiles/r3/ab_ws_placement.jsonl).  With on = 1, the FIRST in-place call of a (plan, stream)
  * whose workspace is 256 MiB or more tries up to three allocations, times the call's first pass into each and keeps the
@@ -282,8 +293,9 @@ size_t mi355fft_plan_workspace_bytes(const mi355fft_plan* plan);
 int mi355fft_plan_trim_workspaces(mi355fft_plan* plan, size_t* freed);
 
 const char* mi355fft_strerror(int status);
-/* Detailed message of the calling thread's most recent failure (the reference's panic text for the
- * validation errors, the HIP error string for MI355FFT_ERR_HIP). */
+/* Detailed message of the calling thread's most recent failure: the reference's panic text for the validation errors; for a failed
+ * transform the status in words and the step that failed -- pass index and kernel name with its grid, the size of the allocation that was
+ * refused with the device's free memory, the HIP runtime's own error string. */
 const char* mi355fft_last_error(void);
 const char* mi355fft_version(void);
 

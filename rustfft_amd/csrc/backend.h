@@ -34,5 +34,11 @@ void stream_destroy(void* s);
 // read + write GB/s of the fastest plain copy this chip does (one float4 per thread, huge grid): the measured data-movement
 // ceiling bench.py quotes next to the 8 TB/s spec (MI355X_MICROARCH.md: 6.29 TB/s); 0 on failure
 double copy_ceiling_gbps(size_t bytes);
+// One cache line of PINNED host memory that kernels of the current device can write (the fused launch's sticky error word): the host
+// reads it without synchronising anything.  *device_ptr = the address kernels use.  nullptr on failure.
+void* host_word_alloc(void** device_ptr);
+void host_word_free(void* host_ptr);
+int cu_count();                                // compute units of the current device as HIP reports them (32 in CPX mode, 256 in SPX); 0 on failure
+int mem_info(size_t* free_bytes, size_t* total_bytes);  // HBM free / total of the current device; 0 on success
 }  // namespace backend
 }  // namespace mi355

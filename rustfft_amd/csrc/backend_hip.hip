@@ -1,6 +1,8 @@
 // HIP implementation of the backend seam (product build).
 #include <hip/hip_runtime.h>
 
+#include <cstring>
+
 #include "backend.h"
 
 namespace mi355 {
@@ -98,6 +100,27 @@ void* stream_create() {
 void stream_destroy(void* s) {
     if (s) (void)hipStreamDestroy((hipStream_t)s);
 }
+void* host_word_alloc(void** device_ptr) {
+    void* h = nullptr;
+    if (fail(hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent))) return nullptr;
+    memset(h, 0, 64);
+    void* d = nullptr;
+    if (fail(hipHostGetDevicePointer(&d, h, 0))) {
+        (void)hipHostFree(h);
+        return nullptr;
+    }
+    *device_ptr = d;
+    return h;
+}
+void host_word_free(void* host_ptr) {
+    if (host_ptr) (void)hipHostFree(host_ptr);
+}
+int cu_count() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return n;
+}
+int mem_info(size_t* free_bytes, size_t* total_bytes) { return fail(hipMemGetInfo(free_bytes, total_bytes)); }
 typedef float copy_v4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void copy_f4_kernel(const copy_v4* __restrict__ in, copy_v4* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

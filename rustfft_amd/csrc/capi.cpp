@@ -26,6 +26,11 @@ int set_err(int status, const std::string& msg) {
     return status;
 }
 int hip_err(int status) { return set_err(status, backend::last_error()); }
+// a failed execute(): the status in words + what plan.cpp recorded about the failing step (pass, kernel, sizes, the runtime's message)
+int exec_err(int status) {
+    const std::string& d = exec_detail();
+    return set_err(status, std::string(mi355fft_strerror(status)) + ": " + (d.empty() ? std::string("execution failed") : d));
+}
 
 int ensure_init() {
     std::lock_guard<std::mutex> g(g_init_mutex);
@@ -133,24 +138,71 @@ int process_host_impl(const mi355fft_plan* cplan, const void* in, size_t n_in, v
         char* d_in = (char*)stage(cx.in, slot_bytes * nslots);
         char* d_out = mode == 0 ? d_in : (char*)stage(cx.out, slot_bytes * nslots);
         if (!d_in || !d_out) return set_err(MI355FFT_ERR_OUT_OF_MEMORY, "device staging allocation failed");
-        std::vector<void*> done(nchunks, nullptr);
-        std::mutex m;
-        std::condition_variable cv;
-        size_t uploaded = 0, downloaded = 0;  // chunks whose kernels are enqueued / whose results are back on the host
-        int rc_main = MI355FFT_OK, rc_dl = MI355FFT_OK;
-        std::string err_dl;
-        bool abort_dl = false;
+        // Shared state of the two threads.  `Pipe`'s destructor is the only way out of this scope: it tells the helper to stop, joins it and
+        // frees the chunk events, so an exception (std::string / std::vector allocation, std::thread start) between the helper's start and
+        // its join unwinds into process_host()'s catch instead of destroying a joinable std::thread (std::terminate).
+        struct Pipe {
+            std::vector<void*> done;
+            std::mutex m;
+            std::condition_variable cv;
+            size_t uploaded = 0, downloaded = 0;  // chunks whose kernels are enqueued / whose results are back on the host
+            int rc_dl = MI355FFT_OK;
+            std::string err_dl;
+            bool abort_dl = false;
+            bool gave_up = false;  // a fused launch of this call gave up a wait: later chunks run one launch per pass
+            std::thread helper;
+            explicit Pipe(size_t n) : done(n, nullptr) {}
+            void stop_helper() {
+                if (!helper.joinable()) return;
+                {
+                    std::lock_guard<std::mutex> lk(m);
+                    abort_dl = true;
+                }
+                cv.notify_all();
+                helper.join();
+            }
+            ~Pipe() {
+                stop_helper();
+                for (void* e : done)
+                    if (e) backend::event_destroy(e);
+            }
+        } pipe(nchunks);
+        int rc_main = MI355FFT_OK;
         const int device = plan.device;
+        // the sticky error word of THIS call's stream slot (nullptr until a fused launch has run on it)
+        auto gave_up_now = [&]() -> bool { return fused_check(plan, cx.stream_a, false) != 0; };
         auto download = [&]() {
             backend::set_device(device);
             for (size_t c = 0; c < nchunks; ++c) {
                 {
-                    std::unique_lock<std::mutex> lk(m);
-                    cv.wait(lk, [&] { return uploaded > c || abort_dl; });
-                    if (abort_dl) return;
+                    std::unique_lock<std::mutex> lk(pipe.m);
+                    pipe.cv.wait(lk, [&] { return pipe.uploaded > c || pipe.abort_dl; });
+                    if (pipe.uploaded <= c) return;  // aborted before this chunk was enqueued
                 }
                 const size_t r0 = c * rows_per_chunk, rows = std::min(rows_per_chunk, batch - r0), slot = (c % nslots) * slot_bytes;
-                int rc = backend::event_sync(done[c]);
+                int rc = backend::event_sync(pipe.done[c]);
+                std::string why;
+                // Chunk c's launches have completed.  If a fused launch of this call has given up a wait by now (chunk c's or a later one that
+                // is already running: the word does not say which), chunk c's device results are not trusted: its rows are still intact in
+                // the caller's `in` (nothing of chunk c has been copied back yet), so they are uploaded again and transformed with one launch
+                // per pass on this thread's own stream.  Chunks checked clean at their own completion stay as they are.
+                if (!rc && gave_up_now()) {
+                    {
+                        std::lock_guard<std::mutex> lk(pipe.m);
+                        pipe.gave_up = true;
+                    }
+                    {
+                        std::lock_guard<std::mutex> turn(g_upload_turn[turn_index(device)]);
+                        rc = backend::h2d(d_in + slot, (const char*)in + r0 * row, rows * row, cx.stream_b) || backend::sync(cx.stream_b);
+                    }
+                    if (!rc) {
+                        const int erc = execute(plan, d_in + slot, d_out + slot, rows, cx.stream_b, mode, nullptr, EXEC_NO_FUSE | EXEC_NO_STICKY_CHECK);
+                        if (erc) {
+                            rc = erc;
+                            why = std::string(mi355fft_strerror(erc)) + ": " + exec_detail();
+                        }
+                    }
+                }
                 std::unique_lock<std::mutex> turn(g_download_turn[turn_index(device)]);
                 if (!rc) rc = backend::d2h((char*)out + r0 * row, d_out + slot, rows * row, cx.stream_b);
                 // the reference's out-of-place variant leaves `input` in an unspecified state; mirror the device buffer back so
@@ -158,24 +210,27 @@ int process_host_impl(const mi355fft_plan* cplan, const void* in, size_t n_in, v
                 if (!rc && mode == 1) rc = backend::d2h((char*)const_cast<void*>(in) + r0 * row, d_in + slot, rows * row, cx.stream_b);
                 if (!rc) rc = backend::sync(cx.stream_b);
                 turn.unlock();
-                std::lock_guard<std::mutex> lk(m);
+                std::lock_guard<std::mutex> lk(pipe.m);
                 if (rc) {
-                    rc_dl = MI355FFT_ERR_HIP;
-                    err_dl = backend::last_error();
+                    pipe.rc_dl = MI355FFT_ERR_HIP;
+                    pipe.err_dl = why.empty() ? backend::last_error() : why;
                 }
-                downloaded = c + 1;
-                cv.notify_all();
+                pipe.downloaded = c + 1;
+                pipe.cv.notify_all();
                 if (rc) return;
             }
         };
-        std::thread helper;
-        if (nchunks > 1) helper = std::thread(download);
+        if (nchunks > 1) pipe.helper = std::thread(download);
         for (size_t c = 0; c < nchunks && rc_main == MI355FFT_OK; ++c) {
             const size_t r0 = c * rows_per_chunk, rows = std::min(rows_per_chunk, batch - r0), slot = (c % nslots) * slot_bytes;
-            if (c >= nslots) {  // the slot's previous chunk must be back on the host first
-                std::unique_lock<std::mutex> lk(m);
-                cv.wait(lk, [&] { return downloaded + nslots > c || rc_dl != MI355FFT_OK; });
-                if (rc_dl != MI355FFT_OK) break;
+            bool unfused = false;
+            {
+                std::unique_lock<std::mutex> lk(pipe.m);
+                if (c >= nslots) {  // the slot's previous chunk must be back on the host first
+                    pipe.cv.wait(lk, [&] { return pipe.downloaded + nslots > c || pipe.rc_dl != MI355FFT_OK; });
+                    if (pipe.rc_dl != MI355FFT_OK) break;
+                }
+                unfused = pipe.gave_up;
             }
             {
                 std::lock_guard<std::mutex> turn(g_upload_turn[turn_index(device)]);
@@ -184,44 +239,33 @@ int process_host_impl(const mi355fft_plan* cplan, const void* in, size_t n_in, v
                     break;
                 }
             }
-            int rc = execute(plan, d_in + slot, d_out + slot, rows, cx.stream_a, mode, nullptr);
+            int rc = execute(plan, d_in + slot, d_out + slot, rows, cx.stream_a, mode, nullptr, EXEC_NO_STICKY_CHECK | (unfused ? EXEC_NO_FUSE : 0));
             if (rc) {
-                rc_main = rc == MI355FFT_ERR_HIP ? hip_err(rc) : set_err(rc, "execution failed");
+                rc_main = exec_err(rc);
                 break;
             }
-            done[c] = backend::event_create();
-            backend::event_record(done[c], cx.stream_a);
+            pipe.done[c] = backend::event_create();
+            backend::event_record(pipe.done[c], cx.stream_a);
             {
-                std::lock_guard<std::mutex> lk(m);
-                uploaded = c + 1;
+                std::lock_guard<std::mutex> lk(pipe.m);
+                pipe.uploaded = c + 1;
             }
-            cv.notify_all();
+            pipe.cv.notify_all();
         }
         if (nchunks > 1) {
-            {
-                std::lock_guard<std::mutex> lk(m);
-                if (rc_main != MI355FFT_OK) abort_dl = true;
+            if (rc_main != MI355FFT_OK) {
+                pipe.stop_helper();
+            } else {
+                pipe.helper.join();  // it ends by itself after the last chunk (or at its first error)
             }
-            cv.notify_all();
-            helper.join();
         } else if (rc_main == MI355FFT_OK) {
             download();
         }
         backend::sync(cx.stream_a);
-        for (void* e : done)
-            if (e) backend::event_destroy(e);
+        // every launch of this call has completed and every chunk was checked at its own completion: the word has served its purpose
+        if (pipe.gave_up || gave_up_now()) fused_check(plan, cx.stream_a, true);
         if (rc_main != MI355FFT_OK) return rc_main;
-        if (rc_dl != MI355FFT_OK) return set_err(rc_dl, err_dl);
-        // a fused two-pass launch bounds its cross-workgroup waits and raises an error word instead of hanging: this path has
-        // just synchronised the stream, so the word is final -- results of a launch that gave up are not handed to the caller as good
-        {
-            StreamSlot& slot = plan.slot_for(cx.stream_a);
-            std::lock_guard<std::mutex> g(slot.launch_mutex);
-            unsigned word = 0;
-            if (slot.pipe.ctrl && (backend::d2h(&word, (const char*)slot.pipe.ctrl + sizeof(unsigned), sizeof(unsigned), cx.stream_a) || backend::sync(cx.stream_a)))
-                return hip_err(MI355FFT_ERR_HIP);
-            if (word) return set_err(MI355FFT_ERR_HIP, "a fused two-pass launch gave up waiting for a dependency (mi355fft_plan_fused_status)");
-        }
+        if (pipe.rc_dl != MI355FFT_OK) return set_err(pipe.rc_dl, pipe.err_dl);
     }
     // a trailing partial chunk is reported after the complete chunks were transformed (array_utils.rs:164-176)
     if (rem != 0) return validation_error(len, n_in, n_out, false);
@@ -352,7 +396,18 @@ size_t mi355fft_bluestein_inner_len(size_t len, int precision) {
 }
 
 int mi355fft_plan_destroy(mi355fft_plan* plan) {
+    if (!plan) return MI355FFT_OK;
+    unsigned word = 0;
+    {
+        // the last chance to report a fused launch that gave up a wait: drain the device (the destructor does the same), then look at every
+        // stream slot's sticky word
+        DeviceGuard dev(plan->p.device);
+        backend::sync_device();
+        word = fused_check(plan->p, nullptr, true, true);
+    }
     delete plan;
+    if (word)
+        return set_err(MI355FFT_ERR_HIP, "a fused two-pass launch of the destroyed plan gave up waiting for a dependency and nobody asked: the results of that call are INVALID");
     return MI355FFT_OK;
 }
 
@@ -387,7 +442,7 @@ static int process_dev(const mi355fft_plan* plan, const void* in, void* out, siz
     if (!plan) return set_err(MI355FFT_ERR_INVALID_ARG, "null plan");
     if (batch && plan->p.len && (!in || !out)) return set_err(MI355FFT_ERR_INVALID_ARG, "null device buffer");
     int rc = execute(const_cast<Plan&>(plan->p), in, out, batch, stream, mode, nullptr);
-    if (rc) return rc == MI355FFT_ERR_HIP ? hip_err(rc) : set_err(rc, "execution failed");
+    if (rc) return exec_err(rc);
     return MI355FFT_OK;
 }
 int mi355fft_process_inplace_dev(const mi355fft_plan* plan, void* buffer, size_t batch, void* stream) {
@@ -413,7 +468,7 @@ int mi355fft_profile_inplace_dev(const mi355fft_plan* plan, void* buffer, size_t
     EventTracer tr(nk);
     for (int r = 0; r < reps; ++r) {
         int rc = execute(p, buffer, buffer, batch, stream, 0, &tr);
-        if (rc) return rc == MI355FFT_ERR_HIP ? hip_err(rc) : set_err(rc, "execution failed");
+        if (rc) return exec_err(rc);
         tr.collect();
     }
     for (int i = 0; i < nk; ++i) ms[i] = (float)(tr.total_ms[i] / reps);
@@ -437,11 +492,14 @@ int mi355fft_plan_fused_status(const mi355fft_plan* plan, void* stream, unsigned
     *error_word = 0;
     Plan& p = const_cast<Plan&>(plan->p);
     DeviceGuard dev(p.device);
-    StreamSlot& slot = p.slot_for(stream);
-    std::lock_guard<std::mutex> g(slot.launch_mutex);
-    if (!slot.pipe.ctrl) return MI355FFT_OK;
-    if (backend::sync(stream) || backend::d2h(error_word, (const char*)slot.pipe.ctrl + sizeof(unsigned), sizeof(unsigned), stream) || backend::sync(stream))
-        return hip_err(MI355FFT_ERR_HIP);
+    if (backend::sync(stream)) return hip_err(MI355FFT_ERR_HIP);  // every launch enqueued on the stream has completed: the word is final
+    *error_word = fused_check(p, stream, true);                  // reported once: the word is cleared
+    return MI355FFT_OK;
+}
+int mi355fft_plan_set_fused_wait_limit(mi355fft_plan* plan, int polls) {
+    if (!plan || polls < 0) return set_err(MI355FFT_ERR_INVALID_ARG, "bad wait limit");
+    plan->p.fuse_spin_limit = polls;
+    if (plan->p.inner) plan->p.inner->fuse_spin_limit = polls;
     return MI355FFT_OK;
 }
 int mi355fft_plan_set_workspace_placement(mi355fft_plan* plan, int on) {
@@ -631,7 +689,7 @@ int multi_process_dev(const mi355fft_multi_plan* mp, const void* const* in, void
         if (rows == 0) return MI355FFT_OK;
         const int m = (mode != 0 && in[g] == out[g]) ? 0 : mode;
         int rc = execute(mp->replicas[g]->p, in[g], out[g], rows, streams ? streams[g] : nullptr, m, nullptr);
-        if (rc) return rc == MI355FFT_ERR_HIP ? hip_err(rc) : set_err(rc, "execution failed");
+        if (rc) return exec_err(rc);
         return MI355FFT_OK;
     });
 }
@@ -736,7 +794,14 @@ int mi355fft_multi_process_immutable_dev(const mi355fft_multi_plan* plan, const 
 }
 int mi355fft_multi_synchronize(const mi355fft_multi_plan* plan, void* const* streams) {
     if (!plan) return set_err(MI355FFT_ERR_INVALID_ARG, "null plan");
-    return on_all_shards(plan, [&](int g) -> int { return backend::sync(streams ? streams[g] : nullptr) ? hip_err(MI355FFT_ERR_HIP) : MI355FFT_OK; });
+    return on_all_shards(plan, [&](int g) -> int {
+        void* st = streams ? streams[g] : nullptr;
+        if (backend::sync(st)) return hip_err(MI355FFT_ERR_HIP);
+        // the shard's launches have completed: a fused launch that gave up a wait is reported here, once (plan.cpp fused_check)
+        if (fused_check(plan->replicas[g]->p, st, true))
+            return set_err(MI355FFT_ERR_HIP, "shard " + std::to_string(g) + ": a fused two-pass launch gave up waiting for a dependency; the results of that call are INVALID");
+        return MI355FFT_OK;
+    });
 }
 int mi355fft_multi_scatter_dev(const mi355fft_multi_plan* plan, const void* root_buffer, int root_device, void* const* buffers, size_t batch, void* const* streams) {
     return multi_edge(plan, buffers, const_cast<void*>(root_buffer), root_device, batch, streams, true);

@@ -64,6 +64,7 @@ template <class T> struct K2FusedParams {
     long long slot_elems;  // elements of a ring slot (n / U)
     int mode;              // bit 0: dependency flags + fences (0 = timing probe only, results undefined); bit 1: work items by ticket
     int spin_limit;        // polls before a wait gives up and sets the error word
+    unsigned* err;         // STICKY error word of the (plan, stream) slot: pinned host memory, never cleared by a launch (plan.cpp fused_check)
 };
 // Passes 0 and 1 of a THREE-pass plan N = R0 R1 R2 through the same kernel.  The tiles of the two passes close into U = R2 / F0 UNITS per
 // transform: unit u is the R1 first-pass tiles with columns [u F0 + j R2, u F0 + j R2 + F0) (j < R1) and the F0 R0 / F1 second-pass tiles

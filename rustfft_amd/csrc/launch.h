@@ -180,8 +180,10 @@ template <class T, class S, int F, bool FIRST, bool SPLIT, int ABL = 0> KernelEn
 // release (buffer_wbl2 sc1: the XCD's L2 writes its dirty lines back), waits for it (the explicit s_waitcnt: the compiler may
 // drop its own) and bumps the slot's counter with a relaxed agent-scope atomic; a consumer's lane 0 polls the counter with
 // relaxed agent-scope loads (L1-bypassing) and s_sleep, then issues ONE agent-scope acquire (invalidates this CU's L1) before
-// the barrier that releases its waves to plain loads.  Waits are bounded: a wait that gives up sets the error word
-// (ctrl[1]) and the tile proceeds -- the launch always terminates; the host checks the word.
+// the barrier that releases its waves to plain loads.  Waits are bounded: a wait that gives up sets the STICKY error word of
+// the (plan, stream) slot (K2FusedParams::err: pinned host memory, cleared by no launch) and the tile proceeds -- the launch always
+// terminates, and the give-up cannot be missed: the next device call / synchronize / destroy on that plan and stream fails with it and the
+// host-slice path re-runs the affected rows as two launches (plan.cpp fused_check, capi.cpp process_host_impl).
 // Deadlock freedom: a work item only waits for items of EARLIER steps, i.e. lower indices.  With tickets (mode bit 1) every
 // lower index has been claimed by a workgroup that is already running when an item starts to wait.  Without tickets the same
 // holds per XCD because a dispatcher walks its share of the grid in order (identical resource needs, nothing to reorder), and
@@ -191,7 +193,9 @@ template <class T> __device__ __forceinline__ void k2f_wait(unsigned* ctr, unsig
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(8);
         if (++spins > fp.spin_limit) {
-            atomicOr(fp.ctrl + 1, 1u);
+            // the word lives in pinned host memory and no launch clears it: a plain system-scope store (no PCIe atomic needed), visible to
+            // the host at the latest when this launch completes
+            __hip_atomic_store(fp.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
         }
     }
@@ -277,6 +281,13 @@ KernelEntry make_k2f(int prec, const char* name, const char* part0, const char* 
     e.prepare = []() -> int {
         return (int)hipFuncSetAttribute((const void*)k2f_kernel<T, S0, F0, SPLIT0, ABL0, S1, F1, SPLIT1, ABL1, RINGV>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)k2f_lds_bytes<T, S0, F0, SPLIT0, ABL0, S1, F1, SPLIT1, ABL1>());
+    };
+    e.blocks_per_cu = []() -> int {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)k2f_kernel<T, S0, F0, SPLIT0, ABL0, S1, F1, SPLIT1, ABL1, RINGV>, k2_threads<S0, F0, ABL0>(),
+                                                         k2f_lds_bytes<T, S0, F0, SPLIT0, ABL0, S1, F1, SPLIT1, ABL1>()) != hipSuccess)
+            return 0;
+        return n;
     };
     return e;
 }
@@ -613,12 +624,12 @@ KernelEntry make_k2f(int prec, const char* name, const char* part0, const char* 
             unsigned* rd = fp.ctrl + 64 + 64 * it.slot;
             cx<T>* ring = fp.pass[0].out + (long long)it.slot * fp.slot_elems;
             if (it.pass == 0) {
-                if (it.use > 0 && *rd < it.use * (unsigned)fp.tiles[1]) fp.ctrl[1] |= 2u;
+                if (it.use > 0 && *rd < it.use * (unsigned)fp.tiles[1]) *fp.err |= 2u;
                 HostExec<T, regs_needed<S0, SPLIT0>()> ex(F0 * S0::TPF);
                 k2_tile<T, S0, F0, true, SPLIT0, ABL0>(ex, fp.pass[0], fp.pass[0].in + it.g * n, ring, it.tile, it.tile_out, lds.data());
                 *written += 1;
             } else {
-                if (*written < (it.use + 1u) * (unsigned)fp.tiles[0]) fp.ctrl[1] |= 2u;
+                if (*written < (it.use + 1u) * (unsigned)fp.tiles[0]) *fp.err |= 2u;
                 HostExec<T, regs_needed<S1, SPLIT1>()> ex(F1 * S1::TPF);
                 k2_tile<T, S1, F1, false, SPLIT1, ABL1>(ex, fp.pass[1], (const cx<T>*)ring, fp.pass[1].out + it.g * n, it.tile, it.tile_out, lds.data());
                 *rd += 1;
@@ -626,6 +637,7 @@ KernelEntry make_k2f(int prec, const char* name, const char* part0, const char* 
         }
     };
     e.prepare = []() -> int { return 0; };
+    e.blocks_per_cu = []() -> int { return F0 * S0::TPF >= 1024 ? 1 : 2; };
     return e;
 }
 template <class T> KernelEntry make_pointwise(int prec) {

@@ -9,6 +9,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdarg>
+#include <cstdio>
 #include <complex>
 #include <cstdlib>
 #include <cstring>
@@ -20,6 +22,28 @@
 #include "kernels_params.h"
 
 namespace mi355 {
+
+// ---- why a call failed (mi355fft_last_error carries it) ----------------------------------------------------------------------
+static thread_local std::string t_detail;
+const std::string& exec_detail() { return t_detail; }
+static int fail_detail(int rc, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+static int fail_detail(int rc, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    t_detail = buf;
+    return rc;
+}
+// a device allocation failed: how much was asked for, what the device has left, and what the runtime said
+static int fail_alloc(const char* what, size_t bytes) {
+    size_t fr = 0, tot = 0;
+    const std::string why = backend::last_error();
+    const bool have = backend::mem_info(&fr, &tot) == 0;
+    return fail_detail(MI355FFT_ERR_OUT_OF_MEMORY, "%s: device allocation of %zu bytes failed (%s); device memory free %zu of %zu bytes%s", what, bytes,
+                       why.c_str(), fr, tot, have ? "" : " (hipMemGetInfo failed too)");
+}
 
 static std::once_flag g_reg_once;
 std::vector<KernelEntry>& registry() {
@@ -228,6 +252,7 @@ Plan::~Plan() {
         PipeState& pp = kv.second->pipe;
         backend::dfree(pp.ring.ptr);
         backend::dfree(pp.ctrl);
+        backend::host_word_free((void*)pp.err_host);
         for (void* s : pp.side) backend::stream_destroy(s);
         for (void* e : pp.ev) backend::event_destroy(e);
         if (pp.ev_fork) backend::event_destroy(pp.ev_fork);
@@ -1231,6 +1256,11 @@ int build_plan(Plan& plan) {
                 if (three && (plan.passes[2].k->n % e.f != 0 || ((long long)plan.passes[0].k->n * e.f) % e.f2 != 0)) continue;
                 if (e.prepare()) return MI355FFT_ERR_HIP;
                 plan.fused = &e;
+                {   // what the chip holds of this kernel: the device's compute units (32 per XCD partition in CPX mode, 256 in SPX) x the
+                    // runtime's occupancy for its registers, LDS and block size -- the in-flight window lag and ring are derived from
+                    const int cus = backend::cu_count(), per = e.blocks_per_cu ? e.blocks_per_cu() : 0;
+                    plan.fuse_resident = (cus > 0 && per > 0) ? cus * per : 256 * (e.threads >= 1024 ? 1 : 2);
+                }
                 if (two && e.aux == 1 && env_int("MI355FFT_FUSE") == 0) plan.fuse_on = true;  // the measured default for this length
                 // three passes: measured for the 256 x 256 pairs (2^23 / 2^24: Complex<f32> +5 % / +3 %, Complex<f64> +21 %,
                 // profiles/r4/ab_fused3_*.jsonl); larger lengths have units beyond what the ring holds in the cache
@@ -1394,6 +1424,10 @@ static int fill_k2_params(const Plan& plan, size_t pi, const void* in, void* out
     }
     return MI355FFT_OK;
 }
+static int grid_too_large(size_t pi, const KernelEntry& k, long long grid, size_t batch) {
+    return fail_detail(MI355FFT_ERR_INVALID_ARG, "pass %zu (%s): %zu rows need a grid of %lld workgroups, above the HIP limit of %lld -- split the call", pi, k.name, batch, grid,
+                       kMaxGrid);
+}
 template <class T>
 static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, size_t batch, void* stream, Tracer* tr, const void* xin = nullptr,
                        void* xout = nullptr) {
@@ -1410,7 +1444,7 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         p.batch = (long long)batch;
         p.sgn = inverse ? (T)-1 : (T)1;
         grid = (long long)((batch + k.f - 1) / k.f);
-        if (grid > kMaxGrid) return MI355FFT_ERR_INVALID_ARG;
+        if (grid > kMaxGrid) return grid_too_large(pi, k, grid, batch);
         k.launch(&p, grid, stream);
     } else if (k.kind == KIND_DYN_K1) {
         DynK1Params<T> p{};
@@ -1421,7 +1455,7 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         p.sgn = inverse ? (T)-1 : (T)1;
         p.s = pd.dyn;
         grid = (long long)((batch + pd.dyn.f - 1) / pd.dyn.f);
-        if (grid > kMaxGrid) return MI355FFT_ERR_INVALID_ARG;
+        if (grid > kMaxGrid) return grid_too_large(pi, k, grid, batch);
         k.launch(&p, grid, stream);
     } else if (k.kind == KIND_DYN_RADER) {
         DynRaderParams<T> p{};
@@ -1435,7 +1469,7 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         p.sgn = inverse ? (T)-1 : (T)1;
         p.s = pd.dyn;
         grid = (long long)((batch + pd.dyn.f - 1) / pd.dyn.f);
-        if (grid > kMaxGrid) return MI355FFT_ERR_INVALID_ARG;
+        if (grid > kMaxGrid) return grid_too_large(pi, k, grid, batch);
         k.launch(&p, grid, stream);
     } else if (k.kind == KIND_BLUESTEIN || k.kind == KIND_BS2_FIRST || k.kind == KIND_BS2_SECOND) {
         BluesteinParams<T> p{};
@@ -1449,7 +1483,7 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         p.n = (int)plan.len;
         p.sgn = inverse ? (T)-1 : (T)1;
         grid = (long long)((batch + k.f - 1) / k.f);
-        if (grid > kMaxGrid) return MI355FFT_ERR_INVALID_ARG;
+        if (grid > kMaxGrid) return grid_too_large(pi, k, grid, batch);
         k.launch(&p, grid, stream);
     } else if (k.kind == KIND_RADER) {
         RaderParams<T> p{};
@@ -1464,14 +1498,15 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         p.sgn = inverse ? (T)-1 : (T)1;
         p.tw2 = (const cx<T>*)pd.d_tw2;
         grid = (long long)((batch + k.f - 1) / k.f);
-        if (grid > kMaxGrid) return MI355FFT_ERR_INVALID_ARG;
+        if (grid > kMaxGrid) return grid_too_large(pi, k, grid, batch);
         k.launch(&p, grid, stream);
     } else {
         K2Params<T> p{};
         const bool general = (k.kind == KIND_K2G_FIRST || k.kind == KIND_K2G_LATER || k.kind >= KIND_K2G_FIRST_CHIRP);  // incl. the prime tiles
-        if (int rc = fill_k2_params<T>(plan, pi, in, out, batch, general, k.f, xin, xout, p)) return rc;
+        if (int rc = fill_k2_params<T>(plan, pi, in, out, batch, general, k.f, xin, xout, p))
+            return fail_detail(rc, "pass %zu (%s): the column-tile parameters do not fit this kernel (m = %lld, s = %lld, tile width %d)", pi, k.name, pd.m, pd.s, k.f);
         grid = (long long)batch * p.tiles_per_fft;
-        if (grid > kMaxGrid) return MI355FFT_ERR_INVALID_ARG;
+        if (grid > kMaxGrid) return grid_too_large(pi, k, grid, batch);
         if ((k.kind == KIND_K2G_FIRST || k.kind == KIND_K2G_LATER) && !(plan.dbg & 2)) {
             p.xq = 3;  // k2g_body: XCD-aware order over the global workgroup index (the placement itself is a compile-time constant there)
             p.xfull = (int)(grid >> 6);
@@ -1479,7 +1514,10 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         k.launch(&p, grid, stream);
     }
     if (tr) tr->after((int)pi, stream);
-    return backend::check_launch() ? MI355FFT_ERR_HIP : MI355FFT_OK;
+    if (backend::check_launch())
+        return fail_detail(MI355FFT_ERR_HIP, "launch of pass %zu (%s: grid %lld x %d threads, %zu bytes of LDS, %zu rows of length %zu) failed: %s", pi, k.name, grid,
+                           k.threads, k.lds_bytes, batch, plan.len, backend::last_error().c_str());
+    return MI355FFT_OK;
 }
 
 
@@ -1595,7 +1633,7 @@ template <class T> static int execute_fused(Plan& plan, const void* in, void* ou
         }
     }
     const size_t steps = batch * (size_t)units, slot_elems = n / (size_t)units;
-    const int resident = 256 * (k.threads >= 1024 ? 1 : 2);  // workgroups the chip holds (128 VGPRs: 16 waves per CU)
+    const int resident = plan.fuse_resident > 0 ? plan.fuse_resident : 256 * (k.threads >= 1024 ? 1 : 2);  // workgroups the chip holds (build_plan)
     const int inflight = (resident + t0 + t1 - 1) / (t0 + t1);
     // measured (profiles/r4/ab_fused_lag_2p*.jsonl): a lag of one in-flight window + 1 leaves second-pass tiles waiting (2^20: 11.3 ms
     // per pair; lag 3: 14.5), two windows do not (11.0), and a ring beyond 128 MiB falls out of the cache's sweet spot (lag 12 / 24
@@ -1611,23 +1649,29 @@ template <class T> static int execute_fused(Plan& plan, const void* in, void* ou
     if (!have_lock) launch_lock = std::unique_lock<std::mutex>(slot.launch_mutex);
     PipeState& pp = slot.pipe;
     const size_t need = (size_t)ns * slot_elems * esz, cbytes = (size_t)k2f_ctrl_words(ns) * sizeof(unsigned);
-    if (pp.ring.bytes < need || pp.ctrl_bytes < cbytes) {
+    if (pp.ring.bytes < need || pp.ctrl_bytes < cbytes || !pp.err_host) {
         backend::sync(stream);
         if (pp.ring.bytes < need) {
             backend::dfree(pp.ring.ptr);
             pp.ring.ptr = backend::dmalloc(need);
             pp.ring.bytes = pp.ring.ptr ? need : 0;
+            if (!pp.ring.ptr) return fail_alloc("ring of the fused two-pass launch", need);
         }
         if (pp.ctrl_bytes < cbytes) {
             backend::dfree(pp.ctrl);
             pp.ctrl = backend::dmalloc(cbytes);
             pp.ctrl_bytes = pp.ctrl ? cbytes : 0;
+            if (!pp.ctrl) return fail_alloc("control block of the fused two-pass launch", cbytes);
         }
-        if (!pp.ring.ptr || !pp.ctrl) return MI355FFT_ERR_OUT_OF_MEMORY;
+        if (!pp.err_host) {
+            pp.err_host = (volatile unsigned*)backend::host_word_alloc(&pp.err_dev);
+            if (!pp.err_host) return fail_detail(MI355FFT_ERR_HIP, "pinned error word of the fused two-pass launch: %s", backend::last_error().c_str());
+        }
     }
     fp.pass[0].out = (cx<T>*)pp.ring.ptr;
     fp.pass[1].in = (const cx<T>*)pp.ring.ptr;
     fp.ctrl = (unsigned*)pp.ctrl;
+    fp.err = (unsigned*)pp.err_dev;
     fp.tiles[0] = t0;
     fp.tiles[1] = t1;
     fp.lag = lag;
@@ -1636,16 +1680,24 @@ template <class T> static int execute_fused(Plan& plan, const void* in, void* ou
     fp.units = units;
     fp.slot_elems = (long long)slot_elems;
     fp.mode = plan.fuse_mode;
-    fp.spin_limit = 1 << 21;  // x s_sleep(8) ~ 0.5 us each: about a second
+    fp.spin_limit = plan.fuse_spin_limit;  // x s_sleep(8) ~ 0.5 us each: about a second by default
     const long long grid = k2f_grid((long long)steps, t0, t1, lag);
-    if (grid > kMaxGrid) return MI355FFT_ERR_INVALID_ARG;
-    if (backend::memset_async(pp.ctrl, 0, cbytes, stream)) return MI355FFT_ERR_HIP;
+    if (grid > kMaxGrid) return grid_too_large(0, k, grid, batch);
+    // ticket and dependency counters start at zero for every launch; the error word is NOT part of the block (PipeState::err_host)
+    if (backend::memset_async(pp.ctrl, 0, cbytes, stream)) return fail_detail(MI355FFT_ERR_HIP, "zeroing the fused launch's control block: %s", backend::last_error().c_str());
     k.launch(&fp, grid, stream);
-    return backend::check_launch() ? MI355FFT_ERR_HIP : MI355FFT_OK;
+    if (backend::check_launch())
+        return fail_detail(MI355FFT_ERR_HIP, "fused launch (%s: grid %lld x %d threads, %zu bytes of LDS, %zu steps, lag %d, %d ring slots) failed: %s", k.name, grid, k.threads,
+                           k.lds_bytes, steps, lag, ns, backend::last_error().c_str());
+#if defined(MI355_EMU)
+    if (env_int("MI355FFT_FUSED_GIVEUP")) *pp.err_host = 1u;  // tests: what a tile whose wait gave up leaves behind
+#endif
+    return MI355FFT_OK;
 }
 
 // mode: 0 in-place (in == out), 1 out-of-place (input may be clobbered), 2 immutable input
-template <class T> static int execute_t(Plan& plan, const void* in, void* out, size_t batch, void* stream, int mode, Tracer* tr) {
+template <class T> static int execute_t(Plan& plan, const void* in, void* out, size_t batch, void* stream, int mode, Tracer* tr, int flags) {
+    const bool may_fuse = plan.fuse_on && plan.fused && tr == nullptr && !(flags & EXEC_NO_FUSE);
     const size_t esz = 2 * sizeof(T);
     const size_t n = plan.len;
     if (batch == 0 || n == 0) return MI355FFT_OK;
@@ -1660,7 +1712,7 @@ template <class T> static int execute_t(Plan& plan, const void* in, void* out, s
         StreamSlot& slot = plan.slot_for(stream);
         std::lock_guard<std::mutex> launch_lock(slot.launch_mutex);
         char* ws = (char*)plan.workspace_in(slot, chunk * M * esz, stream);
-        if (!ws) return MI355FFT_ERR_OUT_OF_MEMORY;
+        if (!ws) return fail_alloc("workspace of the padded rows", chunk * M * esz);
         for (size_t c0 = 0; c0 < batch; c0 += chunk) {
             const size_t rows = std::min(chunk, batch - c0);
             int rc = launch_pass<T>(plan, 0, (const char*)in + c0 * n * esz, ws, rows, stream, c0 == 0 ? tr : nullptr);
@@ -1678,7 +1730,7 @@ template <class T> static int execute_t(Plan& plan, const void* in, void* out, s
         StreamSlot& slot = plan.slot_for(stream);
         std::lock_guard<std::mutex> launch_lock(slot.launch_mutex);
         char* ws = (char*)plan.workspace_in(slot, 2 * chunk * M * esz, stream);
-        if (!ws) return MI355FFT_ERR_OUT_OF_MEMORY;
+        if (!ws) return fail_alloc("workspace of the two inner transforms", 2 * chunk * M * esz);
         char* bufs[2] = {ws, ws + chunk * M * esz};
         for (size_t c0 = 0; c0 < batch; c0 += chunk) {
             const size_t rows = std::min(chunk, batch - c0);
@@ -1704,7 +1756,7 @@ template <class T> static int execute_t(Plan& plan, const void* in, void* out, s
         StreamSlot& slot = plan.slot_for(stream);
         std::lock_guard<std::mutex> launch_lock(slot.launch_mutex);
         char* ws = (char*)plan.workspace_in(slot, chunk * M * esz, stream);
-        if (!ws) return MI355FFT_ERR_OUT_OF_MEMORY;
+        if (!ws) return fail_alloc("workspace of the padded rows", chunk * M * esz);
         for (size_t c0 = 0; c0 < batch; c0 += chunk) {
             const size_t rows = std::min(chunk, batch - c0);
             PointwiseParams<T> pp{};
@@ -1717,25 +1769,25 @@ template <class T> static int execute_t(Plan& plan, const void* in, void* out, s
             pp.tab = (const cx<T>*)pd.d_aux1;
             pp.stage = 0;
             pd.k->launch(&pp, (long long)(rows * M), stream);
-            int rc = execute_t<T>(*plan.inner, ws, ws, rows, stream, 0, nullptr);
+            int rc = execute_t<T>(*plan.inner, ws, ws, rows, stream, 0, nullptr, flags);
             if (rc) return rc;
             pp.in = (const cx<T>*)ws;
             pp.tab = (const cx<T>*)pd.d_aux2;
             pp.stage = 1;
             pd.k->launch(&pp, (long long)(rows * M), stream);
-            rc = execute_t<T>(*plan.inner, ws, ws, rows, stream, 0, nullptr);
+            rc = execute_t<T>(*plan.inner, ws, ws, rows, stream, 0, nullptr, flags);
             if (rc) return rc;
             pp.out = (cx<T>*)((char*)out + c0 * n * esz);
             pp.tab = (const cx<T>*)pd.d_aux1;
             pp.stage = 2;
             pd.k->launch(&pp, (long long)(rows * n), stream);
-            if (backend::check_launch()) return MI355FFT_ERR_HIP;
+            if (backend::check_launch()) return fail_detail(MI355FFT_ERR_HIP, "pointwise pass of the large Bluestein plan (inner length %zu) failed: %s", M, backend::last_error().c_str());
         }
         return MI355FFT_OK;
     }
     const size_t P = plan.passes.size();
     if (P == 1) return launch_pass<T>(plan, 0, in, out, batch, stream, tr);
-    if (plan.fuse_on && plan.fused && tr == nullptr && P == 2) {
+    if (may_fuse && P == 2) {
         const int rcf = execute_fused<T>(plan, in, out, batch, stream, false);
         if (rcf != MI355FFT_ERR_UNSUPPORTED) return rcf;  // a batch too small to pipeline runs as two launches
     }
@@ -1758,7 +1810,7 @@ template <class T> static int execute_t(Plan& plan, const void* in, void* out, s
         StreamSlot& slot = plan.slot_for(stream);
         launch_lock = std::unique_lock<std::mutex>(slot.launch_mutex);
         ws = (char*)plan.workspace_in(slot, chunk * n * esz, stream);
-        if (!ws) return MI355FFT_ERR_OUT_OF_MEMORY;
+        if (!ws) return fail_alloc("workspace of a multi-pass plan", chunk * n * esz);
         // Workspace placement (OPT-IN: mi355fft_plan_set_workspace_placement).  Identical kernels on identical data run 3 - 4 % apart
         // depending on WHICH device allocation the workspace is (measured in one process: eight plans of 2^20 x 1024, each with its own
         // 8 GiB workspace, fall into two groups, 5.61 / 5.52 TB/s and 5.42 / 5.32, independent of the workspace's offset inside its
@@ -1817,7 +1869,7 @@ template <class T> static int execute_t(Plan& plan, const void* in, void* out, s
         }
         const char* src = cin;
         size_t p0 = 0;
-        if (plan.fuse_on && plan.fused && tr == nullptr && P == 3 && plan.kind == PLAN_MACRO) {
+        if (may_fuse && P == 3 && plan.kind == PLAN_MACRO) {
             // passes 0 and 1 in one launch, cin -> A (never back into the caller's input: see execute_fused); the third pass reads A
             const int rcf = execute_fused<T>(plan, cin, A, cb, stream, need_ws);
             if (rcf != MI355FFT_ERR_UNSUPPORTED) {
@@ -1836,10 +1888,31 @@ template <class T> static int execute_t(Plan& plan, const void* in, void* out, s
     return MI355FFT_OK;
 }
 
-int execute(Plan& plan, const void* in, void* out, size_t batch, void* stream, int mode, Tracer* tr) {
+unsigned fused_check(Plan& plan, void* stream, bool clear, bool all_streams) {
+    unsigned word = 0;
+    std::lock_guard<std::mutex> g(plan.ws_mutex);  // the map; err_host itself is written once (under the slot's launch lock) and only ever read here
+    for (auto& kv : plan.slots) {
+        if (!all_streams && kv.first != stream) continue;
+        volatile unsigned* w = kv.second->pipe.err_host;
+        if (!w) continue;
+        word |= *w;
+        if (clear && *w) *w = 0;
+    }
+    if (plan.inner) word |= fused_check(*plan.inner, stream, clear, all_streams);
+    return word;
+}
+
+int execute(Plan& plan, const void* in, void* out, size_t batch, void* stream, int mode, Tracer* tr, int flags) {
+    t_detail.clear();
+    // A fused launch enqueued earlier on this plan and stream gave up a dependency wait (launch.h k2f_wait): what it wrote is invalid, and the
+    // caller of an asynchronous entry point can only learn it here -- this call fails INSTEAD of running (src/lib.rs:184: an Fft is never silently wrong)
+    if ((plan.fused || plan.inner) && !(flags & EXEC_NO_STICKY_CHECK) && fused_check(plan, stream, true))
+        return fail_detail(MI355FFT_ERR_HIP,
+                           "an earlier fused two-pass launch of this plan on this stream gave up waiting for a dependency (device oversubscribed?): the results of that "
+                           "call are INVALID; this call was not run.  Re-run both, or mi355fft_plan_set_fused(plan, 0) for one launch per pass");
     DeviceGuard dev(plan.device);  // launches and workspace allocations go to the device that holds the tables
-    return plan.prec == 32 ? execute_t<float>(plan, in, out, batch, stream, mode, tr)
-                           : execute_t<double>(plan, in, out, batch, stream, mode, tr);
+    return plan.prec == 32 ? execute_t<float>(plan, in, out, batch, stream, mode, tr, flags)
+                           : execute_t<double>(plan, in, out, batch, stream, mode, tr, flags);
 }
 
 }  // namespace mi355

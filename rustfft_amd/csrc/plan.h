@@ -66,8 +66,12 @@ struct PipeState {
     std::vector<void*> side;
     std::vector<void*> ev;
     void* ev_fork = nullptr;
-    void* ctrl = nullptr;  // fused two-pass kernel: control block (ticket, error word, per-slot counters)
+    void* ctrl = nullptr;  // fused two-pass kernel: control block (ticket, per-slot counters), zeroed in front of every launch
     size_t ctrl_bytes = 0;
+    // fused two-pass kernel: the slot's STICKY error word -- pinned host memory a tile writes when one of its bounded waits gives up
+    // (launch.h k2f_wait).  No launch clears it; the host reads it without synchronising (fused_check) and clears it when it reports it.
+    volatile unsigned* err_host = nullptr;
+    void* err_dev = nullptr;  // the same word as kernels address it
 };
 struct StreamSlot {
     std::mutex launch_mutex;
@@ -102,6 +106,8 @@ struct Plan {
     bool fuse_on = false;
     bool fuse_default = false;  // the planner's measured choice for this plan (mi355fft_plan_set_fused(-1) restores it)
     int fuse_mode = 3, fuse_lag = 0, fuse_slots = 0;  // mode 3: dependency counters + work items by ticket
+    int fuse_resident = 0;           // workgroups of the fused kernel the plan's device holds at once: compute units x the runtime's occupancy
+    int fuse_spin_limit = 1 << 21;   // polls (x s_sleep(8) ~ 0.5 us) before a dependency wait gives up: about a second (mi355fft_plan_set_fused_wait_limit)
     // mi355fft_plan_options (host planner in charge): algorithm family, twiddle source, finished tables
     int algorithm = 0;
     mi355fft_twiddle_fn tw_fn = nullptr;
@@ -145,7 +151,17 @@ int build_plan(Plan& plan);
 // Validates plan.recipe against plan.len and derives family / split / inner length (0 or MI355FFT_ERR_INVALID_ARG; *why = reason)
 int apply_recipe(Plan& plan, const char** why);
 size_t bluestein_inner_len(size_t len, int prec);
-int execute(Plan& plan, const void* in, void* out, size_t batch, void* stream, int mode, Tracer* tr);
+// flags of execute()
+enum { EXEC_NO_FUSE = 1,          // run a fused plan as one launch per pass for this call
+       EXEC_NO_STICKY_CHECK = 2   // the caller looks after the slot's sticky error word itself (host-slice path: it re-runs rows instead of failing)
+};
+int execute(Plan& plan, const void* in, void* out, size_t batch, void* stream, int mode, Tracer* tr, int flags = 0);
+// Sticky error word of the plan's slot for `stream` (launch.h k2f_wait): nonzero = a fused launch enqueued on that stream since the last report
+// gave up a wait, its results are INVALID.  Reads pinned host memory, never blocks; `clear` resets the word (a launch still running may set
+// it again -- the next check reports that).  all_streams: any slot of the plan.
+unsigned fused_check(Plan& plan, void* stream, bool clear, bool all_streams = false);
+// why the last execute() / build_plan() of the calling thread failed: pass, kernel, sizes, the runtime's own message ("" when it did not fail)
+const std::string& exec_detail();
 
 }  // namespace mi355
 

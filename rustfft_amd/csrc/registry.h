@@ -39,6 +39,8 @@ struct KernelEntry {
     int (*prepare)();  // one-time setup (dynamic-LDS attribute); returns 0 on success
     const char* part[2];  // KIND_K2_FUSED: names of the first-pass and second-pass kernels this entry fuses
     int f2;               // KIND_K2_FUSED: tile width of the second pass (f = the first pass's)
+    int (*blocks_per_cu)();  // KIND_K2_FUSED: workgroups of this kernel one compute unit holds (the runtime's occupancy calculation over the
+                             // kernel's registers, LDS and block size); nullptr elsewhere
 };
 
 std::vector<KernelEntry>& registry();

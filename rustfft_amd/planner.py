@@ -245,8 +245,13 @@ class Fft:
     def is_fused(self):
         return bool(self._lib.mi355fft_plan_is_fused(self._h))
 
+    def set_fused_wait_limit(self, polls):
+        """Polls (about half a microsecond each) before a dependency wait of a fused launch gives up; 0 = at once (tests)."""
+        self._check(self._lib.mi355fft_plan_set_fused_wait_limit(self._h, int(polls)))
+
     def fused_status(self):
-        """Error word of the plan's most recent fused two-pass launch on torch's current stream (synchronises it); 0 = fine."""
+        """Sticky error word of the plan's fused two-pass launches on torch's current stream since the last report (synchronises the stream,
+        clears the word); 0 = every dependency was met in time."""
         w = ctypes.c_uint(0)
         self._check(self._lib.mi355fft_plan_fused_status(self._h, self._stream(), ctypes.byref(w)))
         return int(w.value)

@@ -119,6 +119,7 @@ pub mod ffi {
         pub fn mi355fft_plan_set_fused(plan: *mut Mi355Plan, mode: c_int) -> c_int;
         pub fn mi355fft_plan_is_fused(plan: *const Mi355Plan) -> c_int;
         pub fn mi355fft_plan_fused_status(plan: *const Mi355Plan, stream: *mut c_void, error_word: *mut c_uint) -> c_int;
+        pub fn mi355fft_plan_set_fused_wait_limit(plan: *mut Mi355Plan, polls: c_int) -> c_int;
         pub fn mi355fft_plan_set_workspace_placement(plan: *mut Mi355Plan, on: c_int) -> c_int;
         pub fn mi355fft_plan_set_chunk_batch(plan: *mut Mi355Plan, chunk_batch: usize) -> c_int;
         pub fn mi355fft_plan_workspace_bytes(plan: *const Mi355Plan) -> usize;
@@ -511,9 +512,17 @@ mod hip {
             if unsafe { ffi::mi355fft_device_count() } <= 0 || unsafe { ffi::mi355fft_init(0) } != 0 {
                 return Err(());
             }
-            // every visible gfx950 device: with more than one, plans shard their batch rows across all of them
-            let devices: Vec<c_int> = (0..unsafe { ffi::mi355fft_device_count() }).collect();
-            Ok(Self { cache: HashMap::new(), precision, fallback: rustfft::FftPlanner::new(), devices })
+            // ONE device, like every other back-end planner of the reference: a rank-per-GPU job must not create contexts, tables and
+            // worker threads on its neighbours' GPUs, and a batch of one must not pay a worker-thread hop.  Sharding over the node is
+            // opt-in: `new_multi()` / `with_devices()`.
+            Ok(Self { cache: HashMap::new(), precision, fallback: rustfft::FftPlanner::new(), devices: vec![0] })
+        }
+        /// Every visible gfx950 device: plans shard their batch rows across all of them (`HipFftMulti`: one replica, one worker thread
+        /// and one staging pool per device and per planned (len, direction) -- meant for a process that owns the whole node).
+        pub fn new_multi() -> Result<Self, ()> {
+            let mut p = Self::new()?;
+            p.devices = (0..unsafe { ffi::mi355fft_device_count() }).collect();
+            Ok(p)
         }
         /// The same over an explicit device list (an ordinal may repeat: each entry is one shard).
         pub fn with_devices(devices: &[i32]) -> Result<Self, ()> {

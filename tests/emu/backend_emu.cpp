@@ -50,6 +50,9 @@ int set_device(int d) {
     return 0;
 }
 void* dmalloc(size_t bytes) {
+    // MI355_EMU_MAX_ALLOC=bytes: larger "device" allocations fail (tests of the out-of-memory reporting)
+    if (const char* e = getenv("MI355_EMU_MAX_ALLOC"))
+        if (bytes > (size_t)atoll(e)) return nullptr;
     void* p = nullptr;
     if (posix_memalign(&p, 64, bytes ? bytes : 64)) return nullptr;
     memset(p, 0x7f, bytes);  // poison
@@ -94,7 +97,7 @@ int memset_async(void* d, int value, size_t bytes, void*) {
 }
 int sync_device() { return 0; }
 int check_launch() { return 0; }
-std::string last_error() { return "emu: a copy touched memory of another (fake) device than the calling thread's current one"; }
+std::string last_error() { return "emu: a copy touched memory of another (fake) device than the calling thread's current one, or an allocation above MI355_EMU_MAX_ALLOC"; }
 void* event_create() { return (void*)1; }
 void event_destroy(void*) {}
 void event_record(void*, void*) {}
@@ -105,5 +108,16 @@ void* event_create_notiming() { return (void*)1; }
 void* stream_create() { return (void*)2; }
 void stream_destroy(void*) {}
 double copy_ceiling_gbps(size_t) { return 0.0; }
+void* host_word_alloc(void** device_ptr) {
+    void* p = calloc(64, 1);
+    *device_ptr = p;
+    return p;
+}
+void host_word_free(void* p) { free(p); }
+int cu_count() { return 256; }
+int mem_info(size_t* f, size_t* t) {
+    *f = *t = (size_t)288 << 30;
+    return 0;
+}
 }  // namespace backend
 }  // namespace mi355

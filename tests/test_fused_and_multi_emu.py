@@ -306,3 +306,100 @@ def test_general_split_prefers_full_tiles(emu_lib, oracle, dtype):
             check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=2)
     if dtype == np.complex64:
         assert planner.plan_fft_forward(4225).describe().startswith("k2gfirst<169,"), planner.plan_fft_forward(4225).describe()
+
+
+# ---- round 5: a fused launch that gives up a wait cannot be missed; failures say why -----------------------------------------------
+def _dev_call(fft, arr, batch):
+    """mi355fft_process_inplace_dev on emulator "device" memory (= host memory), default stream."""
+    return fft._lib.mi355fft_process_inplace_dev(fft._h, arr.ctypes.data_as(ctypes.c_void_p), batch, None)
+
+
+def test_fused_giveup_fails_the_next_device_call_and_is_reported_once(emu_lib):
+    """launch.h k2f_wait: a wait that gives up raises the (plan, stream) slot's STICKY word; no launch clears it.  The asynchronous entry
+    points cannot know at enqueue time -- the NEXT device call on that plan and stream fails with the reason instead of running
+    (include/mi355fft.h; the reference's contract: src/lib.rs:184, an Fft is never silently wrong).  MI355FFT_FUSED_GIVEUP makes the
+    emulator leave the word a gave-up tile leaves."""
+    n, batch = 1 << 16, 136  # (the default ring at 2^16 has 128 slots: smaller batches run as two launches)
+    fus = _planner(emu_lib).plan_fft_forward(n)
+    assert fus.is_fused()
+    x = random_signal(n * batch, np.complex64)
+    want = x.copy()
+    ref = _planner(emu_lib).plan_fft_forward(n)
+    ref.set_fused(0)
+    ref.process(want)
+    a = x.copy()
+    assert _with_env({"MI355FFT_FUSED_GIVEUP": 1}, lambda: _dev_call(fus, a, batch)) == 0  # enqueued fine; the give-up happens "on the device"
+    b = x.copy()
+    rc = _dev_call(fus, b, batch)
+    msg = emu_lib.mi355fft_last_error().decode()
+    assert rc == 8 and "gave up waiting for a dependency" in msg and "INVALID" in msg, (rc, msg)
+    assert np.array_equal(b, x), "the failing call must not have run"
+    assert _dev_call(fus, b, batch) == 0 and np.array_equal(b, want)  # reported once: the plan works again
+    assert fus.fused_status() == 0
+    # the explicit query reports (and clears) it as well
+    _with_env({"MI355FFT_FUSED_GIVEUP": 1}, lambda: _dev_call(fus, x.copy(), batch))
+    assert fus.fused_status() == 1 and fus.fused_status() == 0
+    # and so does destroying the plan when nobody asked
+    h = ctypes.c_void_p()
+    assert emu_lib.mi355fft_plan_create(n, 0, 32, ctypes.byref(h)) == 0
+    c = x.copy()
+    assert _with_env({"MI355FFT_FUSED_GIVEUP": 1}, lambda: emu_lib.mi355fft_process_inplace_dev(h, c.ctypes.data_as(ctypes.c_void_p), batch, None)) == 0
+    assert emu_lib.mi355fft_plan_destroy(h) == 8 and "gave up" in emu_lib.mi355fft_last_error().decode()
+
+
+@pytest.mark.parametrize("chunk_kib,batch", [(0, 160), (65536, 288)])
+def test_fused_giveup_on_host_slices_reruns_the_rows(emu_lib, chunk_kib, batch):
+    """The host-slice path (the literal drop-in for `&mut [Complex<T>]`) checks the word when a chunk's launches have completed and, when it
+    is set, transforms the chunk's rows again from the caller's (still intact) input with one launch per pass: the call SUCCEEDS with
+    correct results in all three API modes, one chunk or a pipeline of chunks, and leaves no stale word behind."""
+    n = 1 << 16
+    fus = _planner(emu_lib).plan_fft_forward(n)
+    ref = _planner(emu_lib).plan_fft_forward(n)
+    ref.set_fused(0)
+    x = random_signal(n * batch, np.complex64)
+    want = x.copy()
+    ref.process(want)
+    env = {"MI355FFT_FUSED_GIVEUP": 1}
+    if chunk_kib:
+        env["MI355FFT_HOST_CHUNK_KIB"] = chunk_kib  # 64 MiB: chunks of 128, 128 and 32 rows -- two fused (the ring has 128 slots), the last as two launches
+
+    def run():
+        a = x.copy()
+        fus.process(a)
+        assert np.array_equal(a, want), "in place"
+        src, out = x.copy(), np.empty_like(x)
+        fus.process_immutable_with_scratch(src, out)
+        assert np.array_equal(out, want) and np.array_equal(src, x), "immutable"
+        fus.process_outofplace_with_scratch(src, out)
+        assert np.array_equal(out, want), "out of place"
+
+    _with_env(env, run)
+    assert fus.fused_status() == 0
+    run()  # and without the injected give-up the same plan still runs fused and right
+
+
+def test_multi_synchronize_reports_a_fused_giveup(emu_lib):
+    n, batch = 1 << 16, 272
+    mp = ctypes.c_void_p()
+    devs = (ctypes.c_int * 2)(0, 0)
+    assert emu_lib.mi355fft_multi_plan_create(n, 0, 32, None, devs, 2, ctypes.byref(mp)) == 0
+    x = random_signal(n * batch, np.complex64)
+    halves = [x[: n * 136].copy(), x[n * 136:].copy()]
+    ptrs = (ctypes.c_void_p * 2)(*[h.ctypes.data_as(ctypes.c_void_p) for h in halves])
+    assert _with_env({"MI355FFT_FUSED_GIVEUP": 1}, lambda: emu_lib.mi355fft_multi_process_inplace_dev(mp, ptrs, batch, None)) == 0
+    assert emu_lib.mi355fft_multi_synchronize(mp, None) == 8 and "gave up" in emu_lib.mi355fft_last_error().decode()
+    assert emu_lib.mi355fft_multi_synchronize(mp, None) == 0
+    assert emu_lib.mi355fft_multi_plan_destroy(mp) == 0
+
+
+def test_a_failed_transform_says_which_step_and_why(emu_lib):
+    """`execution failed` dropped the status.  A refused workspace allocation now names the allocation, its size and what
+    the device had left; the status in words leads the message."""
+    n, batch = 1 << 17, 4
+    fft = _planner(emu_lib).plan_fft_forward(n)
+    fft.set_fused(0)
+    x = random_signal(n * batch, np.complex64)
+    rc = _with_env({"MI355_EMU_MAX_ALLOC": 1 << 20}, lambda: _dev_call(fft, x, batch))
+    msg = emu_lib.mi355fft_last_error().decode()
+    assert rc == 9 and msg.startswith("out of device memory: workspace of a multi-pass plan: device allocation of %d bytes failed" % (n * batch * 8)) and "free" in msg, (rc, msg)
+    assert _dev_call(fft, x, batch) == 0  # and the plan is usable afterwards

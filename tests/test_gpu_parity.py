@@ -1156,3 +1156,186 @@ def test_bench_via_cabi_two_shards_on_one_gpu():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     assert "FAILED" not in line["check"] and line["config"]["finite"]
+
+
+# ---- round 5 ---------------------------------------------------------------------------------------------------------------------
+def _lengths_file(name):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return [int(v) for v in open(os.path.join(root, "tools", "r4", name)).read().replace(",", " ").split()]
+
+
+def test_soak_300_mixed_lengths_in_one_process(planners):
+    """two round-4 sweeps died with `execution failed` at n = 603680 (three general passes) and n = 1176121 (multi-kernel
+    Rader) after ~175 / ~87 lengths in ONE process.  The reference never fails a planned length (src/plan.rs:289-295).  The same 300
+    lengths (general two- to four-pass plans, prime tile heights, multi-kernel Rader primes), each planned and run in place over a 1 GiB
+    buffer in this one process with the workspaces trimmed in between as the sweeps did, two rows of every length against numpy
+    complex128; the device's free memory is watched (a leak is what would make a later allocation fail)."""
+    import torch
+
+    import rustfft_amd
+
+    lengths = _lengths_file("general_f32_lengths.txt") + _lengths_file("prime_tile_rader_large_lengths.txt")
+    assert len(lengths) >= 300 and 603680 in lengths and 1176121 in lengths
+    planner = rustfft_amd.FftPlanner(np.complex64)
+    x = torch.empty((1 << 30) // 8, dtype=torch.complex64, device="cuda")
+    free0 = torch.cuda.mem_get_info()[0]
+    rng = np.random.default_rng(5)
+    worst = (0.0, 0)
+    for i, n in enumerate(lengths):
+        batch = x.numel() // n
+        buf = x[: batch * n]
+        torch.view_as_real(buf).uniform_(-1.0, 1.0)
+        rows = [0, int(rng.integers(0, batch))]
+        want = [np.fft.fft(buf[r * n:(r + 1) * n].cpu().numpy().astype(np.complex128)) for r in rows]
+        fft = planner.plan_fft_forward(n)
+        try:
+            fft.process(buf)
+            torch.cuda.synchronize()
+        except rustfft_amd.FftPanic as e:  # the message must say which step failed and why
+            raise AssertionError(f"length {n} (#{i}, {fft.describe()}): {e}; free device memory {torch.cuda.mem_get_info()[0]} of {free0} at the start") from e
+        for r, w in zip(rows, want):
+            err = rel_l2(buf[r * n:(r + 1) * n].cpu().numpy(), w)
+            worst = max(worst, (err, n))
+            assert err < 5e-6, (n, r, err, fft.describe())
+        fft.trim_workspaces()
+    lost = free0 - torch.cuda.mem_get_info()[0]
+    assert lost < (8 << 30), f"{lost} bytes of device memory gone after 300 trimmed plans (tables only are expected)"
+    print("soak: worst rel L2", worst, "device memory held by 300 plans' tables", lost)
+
+
+@pytest.mark.parametrize("dtype,log2n,batch", [(np.complex64, 20, 64), (np.complex128, 19, 48), (np.complex64, 23, 16)])
+def test_fused_giveup_cannot_be_missed_on_the_device(planners, dtype, log2n, batch):
+    """VERDICT r4 weak 2 / ADVICE r4: a fused launch whose wait gave up used to return success with wrong data on the `_dev` path.  With the
+    wait limit at 0 every dependency that is not already met gives up (include/mi355fft.h mi355fft_plan_set_fused_wait_limit) -- a healthy
+    device then produces real give-ups: the sticky word is raised, the NEXT device call on the plan and stream fails without running, the
+    explicit status reports and clears it, host slices come back CORRECT (the rows are re-run as one launch per pass), and with the limit
+    restored the plan is as good as new."""
+    import torch
+
+    import rustfft_amd
+
+    n = 1 << log2n
+    tdt = torch.complex64 if dtype == np.complex64 else torch.complex128
+    fft = rustfft_amd.FftPlanner(dtype).plan_fft_forward(n)
+    ref = rustfft_amd.FftPlanner(dtype).plan_fft_forward(n)
+    ref.set_fused(0)
+    assert fft.is_fused() and not ref.is_fused()
+    x = torch.empty(batch * n, dtype=tdt, device="cuda")
+    torch.view_as_real(x).uniform_(-1.0, 1.0)
+    want = x.clone()
+    ref.process(want)
+    fft.set_fused_wait_limit(0)
+    gave_up = 0
+    for _ in range(5):
+        y = x.clone()
+        fft.process(y)  # enqueues fine whatever happens on the device
+        torch.cuda.synchronize()
+        z = x.clone()
+        try:
+            fft.process(z)
+        except rustfft_amd.FftPanic as e:
+            gave_up += 1
+            assert e.status == 8 and "gave up waiting for a dependency" in str(e) and "INVALID" in str(e), str(e)
+            assert torch.equal(torch.view_as_real(z), torch.view_as_real(x)), "the failing call must not have run"
+        else:  # no wait of the first call gave up: then its results are right
+            assert torch.equal(torch.view_as_real(y), torch.view_as_real(want))
+        fft.fused_status()  # (clears whatever the second call left)
+    assert gave_up >= 1, "a wait limit of 0 produced no give-up in five launches: the test does not exercise the path"
+    y = x.clone()
+    fft.process(y)
+    assert fft.fused_status() == 1 and fft.fused_status() == 0  # reported once
+    # host slices: the call succeeds with correct rows although its fused launches gave up
+    hx = x.cpu().numpy()
+    hwant = want.cpu().numpy()
+    a = hx.copy()
+    fft.process(a)
+    assert np.array_equal(a, hwant), "in place"
+    out = np.empty_like(hx)
+    fft.process_immutable_with_scratch(hx, out)
+    assert np.array_equal(out, hwant), "immutable"
+    src = hx.copy()
+    fft.process_outofplace_with_scratch(src, out)
+    assert np.array_equal(out, hwant), "out of place"
+    assert fft.fused_status() == 0
+    fft.set_fused_wait_limit(1 << 21)
+    for _ in range(3):
+        y = x.clone()
+        fft.process(y)
+        assert torch.equal(torch.view_as_real(y), torch.view_as_real(want))
+    assert fft.fused_status() == 0
+
+
+_HOG = r"""
+import random, sys, time, torch
+a = torch.empty(1 << 28, dtype=torch.float32, device="cuda"); b = torch.empty_like(a)   # 1 GiB each: HBM traffic
+c = torch.rand(1 << 24, device="cuda")                                                  # CU-bound transcendental chains
+print("ready", flush=True)
+t_end = time.time() + float(sys.argv[1])
+rnd = random.Random(7)
+while time.time() < t_end:
+    for _ in range(rnd.randint(1, 6)):
+        b.copy_(a)
+    for _ in range(rnd.randint(0, 4)):
+        c = torch.sin(c) * 1.0001 + 0.1
+    if rnd.random() < 0.5:
+        torch.cuda.synchronize()
+        time.sleep(rnd.uniform(0.0, 0.004))
+torch.cuda.synchronize()
+"""
+
+
+def test_fused_launch_under_a_second_process(planners):
+    """The guide's protocol for cross-workgroup hand-offs (MI355X_MICROARCH.md, "inter-workgroup visibility"): test under UNEVEN load with the
+    consumer's L1 warm and compare every word.  A second PROCESS hogs HBM and the CUs in bursts with random sleeps while this one runs
+    >= 200 fused launches per size, alternating between two inputs (the ring a launch reads was filled with the OTHER input's intermediate
+    by the launch before: a consumer CU that served a stale L1 line, or a slot rewritten too early, changes words), every output word
+    compared with the two-launch plan's, the sticky error word 0 throughout.  2^16, 2^20, 2^21 (narrow later tile) and the 2^23 unit launch,
+    both precisions."""
+    import subprocess
+    import sys
+
+    import torch
+
+    import rustfft_amd
+
+    hog = subprocess.Popen([sys.executable, "-c", _HOG, "150"], stdout=subprocess.PIPE, text=True)
+    try:
+        assert hog.stdout.readline().strip() == "ready"
+        launches = 0
+        for dtype, tdt in ((np.complex64, torch.complex64), (np.complex128, torch.complex128)):
+            for log2n in (16, 20, 21, 23):
+                n = 1 << log2n
+                batch = max(24, (1 << 28 if dtype == np.complex64 else 1 << 27) // n // (8 if dtype == np.complex64 else 16))
+                fft = rustfft_amd.FftPlanner(dtype).plan_fft_forward(n)
+                ref = rustfft_amd.FftPlanner(dtype).plan_fft_forward(n)
+                ref.set_fused(0)
+                assert fft.is_fused(), (dtype, log2n)
+                xs, wants = [], []
+                for seed in (1, 2):
+                    x = torch.empty(batch * n, dtype=tdt, device="cuda")
+                    torch.view_as_real(x).uniform_(-1.0, 1.0)
+                    w = x.clone()
+                    ref.process(w)
+                    xs.append(x)
+                    wants.append(w)
+                y = torch.empty_like(xs[0])
+                exact = log2n != 21 or dtype != np.complex64  # (f32 2^21: the fused kernel's later tile has another shape -> equal up to rounding; compare launch to launch)
+                firsts = [None, None]
+                for r in range(200):
+                    i = r & 1
+                    fft.process_immutable_with_scratch(xs[i], y)
+                    if exact:
+                        assert torch.equal(torch.view_as_real(y), torch.view_as_real(wants[i])), (dtype, log2n, r)
+                    elif firsts[i] is None:
+                        firsts[i] = y.clone()
+                        assert float((y - wants[i]).abs().max()) <= 4e-7 * float(wants[i].abs().max())
+                    else:
+                        assert torch.equal(torch.view_as_real(y), torch.view_as_real(firsts[i])), (dtype, log2n, r)
+                    if r % 50 == 49:
+                        assert fft.fused_status() == 0, (dtype, log2n, r)
+                    launches += 1
+                assert hog.poll() is None, "the hog process must still be running beside the fused launches"
+        print("fused launches compared under a second process:", launches)
+    finally:
+        hog.kill()
+        hog.wait()
