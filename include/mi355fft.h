@@ -230,6 +230,13 @@ int mi355fft_multi_process_outofplace_dev(const mi355fft_multi_plan* plan, void*
 int mi355fft_multi_process_immutable_dev(const mi355fft_multi_plan* plan, const void* const* inputs, void* const* outputs,
                                          size_t batch, void* const* streams);
 int mi355fft_multi_synchronize(const mi355fft_multi_plan* plan, void* const* streams);
+/* NUMA placement.  Every shard's worker thread (and the download helper of a host-slice call) is bound to the cores of the NUMA node its GPU
+ * is attached to (/sys/bus/pci/devices/<pci id>/numa_node -> /sys/devices/system/node/node<k>/cpulist): the blocking pageable copies of
+ * eight staging pipelines on a two-socket node then never cross the socket interconnect.  Threads of the CALLER are never re-bound; an
+ * unknown node (one socket, no sysfs) leaves the library's threads unbound.  mi355fft_device_cpulist writes that core list ("0-63,128-191",
+ * "" when unknown) and returns its length, or -1 on a bad argument; mi355fft_multi_plan_shard_pinned says whether a shard's worker is bound. */
+int mi355fft_device_cpulist(int device, char* buf, size_t cap);
+int mi355fft_multi_plan_shard_pinned(const mi355fft_multi_plan* plan, int shard);
 /* The optional edges when the whole batch lives on ONE device: peer copies (hipMemcpyPeerAsync over xGMI) of every shard's
  * rows from / to `root_buffer` (batch * len elements on device `root_device`), enqueued on the shards' streams.  The data
  * path itself has no collective; these are bounded by the root's links and are never part of a

@@ -40,5 +40,8 @@ void* host_word_alloc(void** device_ptr);
 void host_word_free(void* host_ptr);
 int cu_count();                                // compute units of the current device as HIP reports them (32 in CPX mode, 256 in SPX); 0 on failure
 int mem_info(size_t* free_bytes, size_t* total_bytes);  // HBM free / total of the current device; 0 on success
+// PCI address of a device as sysfs spells it ("0000:c1:00.0"), "" when unknown: /sys/bus/pci/devices/<id>/numa_node names the socket whose
+// memory and cores are closest to that GPU's host link
+std::string pci_bus_id(int device);
 }  // namespace backend
 }  // namespace mi355

@@ -1,6 +1,7 @@
 // HIP implementation of the backend seam (product build).
 #include <hip/hip_runtime.h>
 
+#include <cctype>
 #include <cstring>
 
 #include "backend.h"
@@ -121,6 +122,13 @@ int cu_count() {
     return n;
 }
 int mem_info(size_t* free_bytes, size_t* total_bytes) { return fail(hipMemGetInfo(free_bytes, total_bytes)); }
+std::string pci_bus_id(int device) {
+    char buf[64] = {0};
+    if (hipDeviceGetPCIBusId(buf, (int)sizeof buf, device) != hipSuccess) return "";
+    std::string id(buf);
+    for (auto& c : id) c = (char)tolower((unsigned char)c);
+    return id;
+}
 typedef float copy_v4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void copy_f4_kernel(const copy_v4* __restrict__ in, copy_v4* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

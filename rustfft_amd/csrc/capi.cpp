@@ -9,6 +9,8 @@
 #include <cstring>
 #include <string>
 #include <thread>
+
+#include <sched.h>
 #include <vector>
 
 #include "backend.h"
@@ -74,6 +76,61 @@ void* stage(Workspace& w, size_t bytes) {
 constexpr int kMaxTurnDevices = 64;
 std::mutex g_upload_turn[kMaxTurnDevices], g_download_turn[kMaxTurnDevices];
 inline int turn_index(int device) { return device >= 0 ? device % kMaxTurnDevices : 0; }
+
+// ---- NUMA placement of the library's own threads ----------------------------------------------------------------------------------
+// A shard worker (and the download helper of the host-slice pipeline) drives blocking pageable copies over ONE GPU's host link; on a
+// two-socket node the staging runs at the link's rate only from the socket the GPU hangs off (the other one adds an inter-socket hop to
+// every copied page).  The threads this library CREATES are therefore bound to the cores of the GPU's NUMA node, read from sysfs:
+// /sys/bus/pci/devices/<pci id>/numa_node -> /sys/devices/system/node/node<k>/cpulist.  Best effort: an unknown node (-1: one socket,
+// a container without sysfs) leaves the thread where the scheduler puts it.  The CALLER's threads are never touched.
+std::string sysfs_root() {
+#if defined(MI355_TUNING) || defined(MI355_EMU)
+    if (const char* e = getenv("MI355FFT_SYSFS_ROOT")) return e;  // tests: a directory that describes a fake two-socket node
+#endif
+    return "/sys";
+}
+std::string read_line(const std::string& path) {
+    std::string out;
+    if (FILE* f = fopen(path.c_str(), "r")) {
+        char buf[4096];
+        if (fgets(buf, sizeof buf, f)) out = buf;
+        fclose(f);
+    }
+    while (!out.empty() && (out.back() == '\n' || out.back() == ' ')) out.pop_back();
+    return out;
+}
+// "0-63,128-191" of the NUMA node device `device` is attached to; "" when it cannot be told
+std::string device_cpulist(int device) {
+    const std::string id = backend::pci_bus_id(device);
+    if (id.empty()) return "";
+    const std::string node = read_line(sysfs_root() + "/bus/pci/devices/" + id + "/numa_node");
+    if (node.empty() || node[0] == '-') return "";
+    return read_line(sysfs_root() + "/devices/system/node/node" + node + "/cpulist");
+}
+bool pin_this_thread(const std::string& cpulist) {
+    if (cpulist.empty()) return false;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int n = 0;
+    const char* p = cpulist.c_str();
+    while (*p) {
+        char* end = nullptr;
+        long a = strtol(p, &end, 10), b = a;
+        if (end == p) break;
+        p = end;
+        if (*p == '-') {
+            b = strtol(p + 1, &end, 10);
+            p = end;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+            if (c >= 0) {
+                CPU_SET((int)c, &set);
+                ++n;
+            }
+        if (*p == ',') ++p;
+    }
+    return n > 0 && sched_setaffinity(0, sizeof set, &set) == 0;
+}
 
 // A staging context of the plan's pool for the duration of one host-slice call.
 struct HostLease {
@@ -171,8 +228,9 @@ int process_host_impl(const mi355fft_plan* cplan, const void* in, size_t n_in, v
         const int device = plan.device;
         // the sticky error word of THIS call's stream slot (nullptr until a fused launch has run on it)
         auto gave_up_now = [&]() -> bool { return fused_check(plan, cx.stream_a, false) != 0; };
-        auto download = [&]() {
+        auto download = [&](bool own_thread) {
             backend::set_device(device);
+            if (own_thread) pin_this_thread(device_cpulist(device));  // the helper this library created, never the caller's thread
             for (size_t c = 0; c < nchunks; ++c) {
                 {
                     std::unique_lock<std::mutex> lk(pipe.m);
@@ -220,7 +278,7 @@ int process_host_impl(const mi355fft_plan* cplan, const void* in, size_t n_in, v
                 if (rc) return;
             }
         };
-        if (nchunks > 1) pipe.helper = std::thread(download);
+        if (nchunks > 1) pipe.helper = std::thread(download, true);
         for (size_t c = 0; c < nchunks && rc_main == MI355FFT_OK; ++c) {
             const size_t r0 = c * rows_per_chunk, rows = std::min(rows_per_chunk, batch - r0), slot = (c % nslots) * slot_bytes;
             bool unfused = false;
@@ -259,7 +317,7 @@ int process_host_impl(const mi355fft_plan* cplan, const void* in, size_t n_in, v
                 pipe.helper.join();  // it ends by itself after the last chunk (or at its first error)
             }
         } else if (rc_main == MI355FFT_OK) {
-            download();
+            download(false);
         }
         backend::sync(cx.stream_a);
         // every launch of this call has completed and every chunk was checked at its own completion: the word has served its purpose
@@ -552,9 +610,11 @@ struct ShardWorker {
     std::condition_variable cv;
     std::deque<std::function<void()>> q;
     bool stop = false;
+    bool pinned = false;
     explicit ShardWorker(int device) {
         th = std::thread([this, device] {
             backend::set_device(device);
+            pinned = pin_this_thread(device_cpulist(device));  // staging copies from the socket the GPU's host link belongs to
             for (;;) {
                 std::function<void()> job;
                 {
@@ -768,6 +828,22 @@ int mi355fft_multi_plan_destroy(mi355fft_multi_plan* plan) {
     return MI355FFT_OK;
 }
 int mi355fft_multi_plan_shards(const mi355fft_multi_plan* plan) { return plan ? (int)plan->replicas.size() : 0; }
+int mi355fft_device_cpulist(int device, char* buf, size_t cap) {
+    if (!buf || cap == 0 || device < 0) return -1;
+    const std::string l = device_cpulist(device);
+    const size_t n = l.size() < cap - 1 ? l.size() : cap - 1;
+    memcpy(buf, l.data(), n);
+    buf[n] = 0;
+    return (int)n;
+}
+int mi355fft_multi_plan_shard_pinned(const mi355fft_multi_plan* plan, int shard) {
+    if (!plan || shard < 0 || shard >= (int)plan->workers.size()) return 0;
+    // the worker binds itself first thing; an empty job through its queue orders this read behind that
+    ShardJoin join(1);
+    plan->workers[shard]->submit([&join] { join.done(MI355FFT_OK); });
+    join.wait();
+    return plan->workers[shard]->pinned ? 1 : 0;
+}
 int mi355fft_multi_plan_device(const mi355fft_multi_plan* plan, int shard) {
     return (plan && shard >= 0 && shard < (int)plan->devices.size()) ? plan->devices[shard] : -1;
 }

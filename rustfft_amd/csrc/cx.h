@@ -111,6 +111,33 @@ template <class T> MI_HD void st_nt(cx<T>* p, cx<T> v) {
 #endif
 }
 
+// the same for a PAIR of adjacent values (16 bytes for Complex<float>: the two-columns-per-lane tiles); C2 = {cx<T> a, b}
+template <class T, class C2> MI_HD C2 ld_nt2(const cx<T>* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef T vec4 __attribute__((ext_vector_type(4)));
+    vec4 t = __builtin_nontemporal_load((const vec4*)p);
+    C2 q;
+    q.a = cx<T>{t.x, t.y};
+    q.b = cx<T>{t.z, t.w};
+    return q;
+#else
+    return *(const C2*)p;
+#endif
+}
+template <class T, class C2> MI_HD void st_nt2(cx<T>* p, const C2& q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef T vec4 __attribute__((ext_vector_type(4)));
+    vec4 t;
+    t.x = q.a.re;
+    t.y = q.a.im;
+    t.z = q.b.re;
+    t.w = q.b.im;
+    __builtin_nontemporal_store(t, (vec4*)p);
+#else
+    *(C2*)p = q;
+#endif
+}
+
 // Agent-scope (device-coherent) accesses for data that another workgroup produces or consumes inside ONE launch (the fused
 // two-pass kernel's ring): relaxed agent-scope atomics lower to global_load / global_store ... sc1 -- the load is served past
 // this CU's L1 (which no other CU's store ever refreshes), the store is written through the XCD's L2 (whose dirty lines no

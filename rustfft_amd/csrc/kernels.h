@@ -225,7 +225,11 @@ MI_HD void k2_tile(X& ex, const K2Params<T>& p, const cx<T>* in, cx<T>* out, uns
                     static_for<0, R0>([&](auto K_) {
                         constexpr int k = K_;
                         const unsigned row = (unsigned)(u + m * TPF + k * NB0);
-                        const cx2 q = *(const cx2*)(in + (col + row * M));
+                        cx2 q;
+                        if constexpr ((ABL & 16) != 0)
+                            q = ld_nt2<T, cx2>(in + (col + row * M));
+                        else
+                            q = *(const cx2*)(in + (col + row * M));
                         v[m * R0 + k] = q.a;
                         v[NREG + m * R0 + k] = q.b;
                     });
@@ -250,7 +254,10 @@ MI_HD void k2_tile(X& ex, const K2Params<T>& p, const cx<T>* in, cx<T>* out, uns
                             cx2 q{v[m * RL + k], v[NREG + m * RL + k]};
                             q.a.im *= sgn_out;
                             q.b.im *= sgn_out;
-                            *(cx2*)(out + (obase + (unsigned)f + (unsigned)(base + k * STL) * s32)) = q;
+                            if constexpr ((ABL & 32) != 0)
+                                st_nt2<T, cx2>(out + (obase + (unsigned)f + (unsigned)(base + k * STL) * s32), q);
+                            else
+                                *(cx2*)(out + (obase + (unsigned)f + (unsigned)(base + k * STL) * s32)) = q;
                         });
                     });
                 }

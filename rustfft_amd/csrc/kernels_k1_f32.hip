@@ -70,6 +70,26 @@ void register_k1_f32(std::vector<KernelEntry>& reg) {
     // load/store skeleton against 5.1 - 5.2 TB/s for the full kernel.  Tuning history (no gain, removed): F = 2 / 8 rows per
     // workgroup, radix-8 schedules, 128-thread 4096 kernel, non-temporal loads/stores (tools/membench shows +11 % for an
     // in-place copy, the real kernels lose 1 - 3 %).
+    // round 5: non-temporal accesses re-measured on the kernels with staged tables (tools/membench/skel4: +3 .. +8 % on this shape):
+    // 50 = loads and stores, 51 = loads only, 52 = stores only (ABL bits 16 / 32 on top of the shipped "t1" = 1024)
+    MI_K1ABL(50, 1072, float, 32, 4, false, 1024, 64, 16, 16, 4);
+    MI_K1ABL(51, 1040, float, 32, 4, false, 1024, 64, 16, 16, 4);
+    MI_K1ABL(52, 1056, float, 32, 4, false, 1024, 64, 16, 16, 4);
+    MI_K1ABL(50, 1072, float, 32, 2, false, 2048, 128, 16, 16, 8);
+    MI_K1ABL(51, 1040, float, 32, 2, false, 2048, 128, 16, 16, 8);
+    MI_K1ABL(52, 1056, float, 32, 2, false, 2048, 128, 16, 16, 8);
+    MI_K1ABL(50, 1072, float, 32, 1, false, 4096, 256, 16, 16, 16);
+    MI_K1ABL(51, 1040, float, 32, 1, false, 4096, 256, 16, 16, 16);
+    MI_K1ABL(52, 1056, float, 32, 1, false, 4096, 256, 16, 16, 16);
+    MI_K1ABL(50, 1072, float, 32, 1, true, 8192, 256, 8, 32, 32);
+    MI_K1ABL(51, 1040, float, 32, 1, true, 8192, 256, 8, 32, 32);
+    MI_K1ABL(52, 1056, float, 32, 1, true, 8192, 256, 8, 32, 32);
+    MI_K1ABL(50, 1072, float, 32, 1, true, 16384, 512, 16, 32, 32);
+    MI_K1ABL(51, 1040, float, 32, 1, true, 16384, 512, 16, 32, 32);
+    MI_K1ABL(52, 1056, float, 32, 1, true, 16384, 512, 16, 32, 32);
+    MI_K1ABL(50, 1072, float, 32, 1, true, 32768, 1024, 32, 32, 32);
+    MI_K1ABL(51, 1040, float, 32, 1, true, 32768, 1024, 32, 32, 32);
+    MI_K1ABL(52, 1056, float, 32, 1, true, 32768, 1024, 32, 32, 32);
     // sub-pass twiddle tables staged in LDS: all (30) / sub-pass 1 only (31) / last sub-pass only (32)
     MI_K1ABL(30, 128, float, 32, 4, false, 1024, 64, 16, 16, 4);
     MI_K1ABL(31, 1024, float, 32, 4, false, 1024, 64, 16, 16, 4);

@@ -64,6 +64,21 @@ void register_k2_f32(std::vector<KernelEntry>& reg) {
     // tuning 60: PERSISTENT workgroups (ABL bit 8192) for the one-workgroup-per-CU 2048-row later tile and, for comparison, the 1024-row tiles
     MI_K2ABL(60, 8192, float, 32, 16, true, 2048, 64, 8, 16, 16);
     MI_K2ABL(60, 8320, float, 32, 16, true, 1024, 32, 8, 8, 16);
+#if defined(MI355_TUNING)
+    // round 5, tuning 70 / 71 / 72: the 2048-row tiles of 2^22 (config 5's per-GPU kernels) with non-temporal loads + stores / loads / stores
+    reg.push_back(make_k2<float, Sched<2048, 64, 8, 16, 16>, 8, true, true, 48>(32, "k2first<2048, 64, 8, 16, 16>xF8nt"));
+    reg.back().variant = 70;
+    reg.push_back(make_k2<float, Sched<2048, 128, 8, 16, 16>, 16, false, true, 4096 + 48>(32, "k2later<2048, 128, 8, 16, 16>xF16p2nt"));
+    reg.back().variant = 70;
+    reg.push_back(make_k2<float, Sched<2048, 64, 8, 16, 16>, 8, true, true, 16>(32, "k2first<2048, 64, 8, 16, 16>xF8ntl"));
+    reg.back().variant = 71;
+    reg.push_back(make_k2<float, Sched<2048, 128, 8, 16, 16>, 16, false, true, 4096 + 16>(32, "k2later<2048, 128, 8, 16, 16>xF16p2ntl"));
+    reg.back().variant = 71;
+    reg.push_back(make_k2<float, Sched<2048, 64, 8, 16, 16>, 8, true, true, 32>(32, "k2first<2048, 64, 8, 16, 16>xF8nts"));
+    reg.back().variant = 72;
+    reg.push_back(make_k2<float, Sched<2048, 128, 8, 16, 16>, 16, false, true, 4096 + 32>(32, "k2later<2048, 128, 8, 16, 16>xF16p2nts"));
+    reg.back().variant = 72;
+#endif
     MI_K2V(10, float, 32, 16, true, 1024, 32, 32, 32);     // tuning: two radix-32 sub-passes, one exchange (the later pass spills)
     MI_K2V(11, float, 32, 16, true, 1024, 32, 4, 16, 16);  // tuning: radix-4 first sub-pass (eight butterflies per thread)
     // ablation probes of the default 1024-row tile (wrong results by design; MI355FFT_VARIANT=5..8, tuning only)

@@ -138,6 +138,26 @@ void ensure_registry() {
         register_smooth2_f64_1(r);
         register_smooth2_f64_2(r);
         register_smooth2_f64_3(r);
+        register_smooth4_f32_0(r);
+        register_smooth4_f32_1(r);
+        register_smooth4_f32_ns0(r);
+        register_smooth4_f32_ns1(r);
+        register_smooth4_f32_ns2(r);
+        register_smooth4_f32_ns3(r);
+        register_smooth4_f32_ns4(r);
+        register_smooth4_f32_ns5(r);
+        register_smooth4_f32_ns6(r);
+        register_smooth4_f32_ns7(r);
+        register_smooth4_f32_ns8(r);
+        register_smooth4_f32_ns9(r);
+        register_smooth4_f64_0(r);
+        register_smooth4_f64_1(r);
+        register_smooth4_f64_2(r);
+        register_smooth4_f64_3(r);
+        register_smooth4_f64_4(r);
+        register_smooth4_f64_5(r);
+        register_smooth4_f64_6(r);
+        register_smooth4_f64_7(r);
         register_smooth3_f32_0(r);
         register_smooth3_f32_1(r);
         register_smooth3_f32_2(r);
@@ -495,7 +515,9 @@ static bool is_prime_sz(size_t n) {
 
 // choose macro radices r_1..r_P (each with a FIRST and a LATER kernel) whose product is n:
 // fewest passes, then the most balanced split, larger radices first.
-static bool choose_macro_radices(int prec, size_t n, std::vector<size_t>& out) {
+// `fused_resplit` (may be null): set when the split was taken ONLY because a default fused kernel exists for it -- build_plan then keeps the
+// balanced split as the plan's unfused form (Plan::unfused_alt); allow_fused_resplit = false builds that form.
+static bool choose_macro_radices(int prec, size_t n, std::vector<size_t>& out, bool allow_fused_resplit = true, bool* fused_resplit = nullptr) {
     std::vector<size_t> avail;
     for (auto& e : registry())
         if (e.kind == KIND_K2_FIRST && e.prec == prec && e.variant == 0 && find_kernel(KIND_K2_LATER, prec, e.n) &&
@@ -537,7 +559,7 @@ static bool choose_macro_radices(int prec, size_t n, std::vector<size_t>& out) {
     if (env_int("MI355FFT_ORDER") == 1) std::reverse(out.begin(), out.end());  // tuning: smallest radix first
     // a two-pass plan whose balanced split has no default fused kernel while ANOTHER split (or pass order) of the same length has one
     // takes that one (Complex<f32>: 2^17 as 256 x 512, 2^18 as 256 x 1024 -- measured, kernels_k2f_f32.hip)
-    if (out.size() == 2 && env_int("MI355FFT_ORDER") == 0) {
+    if (out.size() == 2 && env_int("MI355FFT_ORDER") == 0 && allow_fused_resplit) {
         auto named = [&](int kind, const char* name) -> const KernelEntry* {
             for (auto& e : registry())
                 if (e.kind == kind && e.prec == prec && e.variant == 0 && !strcmp(e.name, name)) return &e;
@@ -556,6 +578,7 @@ static bool choose_macro_radices(int prec, size_t n, std::vector<size_t>& out) {
                 const KernelEntry *kf = named(KIND_K2_FIRST, e.part[0]), *kl = named(KIND_K2_LATER, e.part[1]);
                 if (kf && kl && (size_t)kf->n * (size_t)kl->n == n && fused_auto((size_t)kf->n, (size_t)kl->n)) {
                     out = {(size_t)kf->n, (size_t)kl->n};
+                    if (fused_resplit) *fused_resplit = true;
                     break;
                 }
             }
@@ -951,7 +974,7 @@ template <class T> static int build_plan_t(Plan& plan) {
             }
         }
         // the large-N passes address one transform with 32-bit element offsets
-        if (n < ((size_t)1 << 31) && choose_macro_radices(plan.prec, n, radices)) {
+        if (n < ((size_t)1 << 31) && choose_macro_radices(plan.prec, n, radices, !plan.no_fused_resplit, &plan.fused_resplit)) {
             plan.kind = PLAN_MACRO;
             return macro_passes(radices, false);
         }
@@ -1268,10 +1291,31 @@ int build_plan(Plan& plan) {
                 plan.fuse_default = (two && e.aux == 1) || (three && e.aux == 1 && plan.len <= ((size_t)1 << 24));
                 if (e.variant != 0) break;  // tuning: the requested ring-access variant wins over the default
             }
+    // a split taken only for its fused kernel (Complex<f32> 2^17 as 256 x 512, 2^18 as 256 x 1024, 2^21 as 1024 x 2048) is slower than the
+    // balanced one whenever the fused launch cannot run -- a batch with fewer transforms than the ring has slots (the common interactive case),
+    // mi355fft_plan_set_fused(plan, 0): 6.33 against 5.92 ms at 2^18.  Such a plan keeps BOTH pass sets: the balanced split as a second plan
+    // object (tables only: a few hundred KiB) that execute() takes when it is not going to fuse.
+    if (plan.fused_resplit && !plan.no_fused_resplit && plan.fused && plan.fuse_default && plan.kind == PLAN_MACRO && two) {
+        std::unique_ptr<Plan> alt(new Plan());
+        alt->len = plan.len;
+        alt->direction = plan.direction;
+        alt->prec = plan.prec;
+        alt->algorithm = plan.algorithm;
+        alt->tw_fn = plan.tw_fn;
+        alt->tw_ctx = plan.tw_ctx;
+        alt->no_fused_resplit = true;
+        if (int arc = build_plan(*alt)) return arc;
+        alt->tw_fn = nullptr;
+        alt->tw_ctx = nullptr;
+        alt->fuse_on = false;
+        alt->fuse_default = false;
+        if (alt->kind == PLAN_MACRO && alt->passes.size() == 2) plan.unfused_alt = std::move(alt);
+    }
     return MI355FFT_OK;
 }
 
 std::string Plan::describe() const {
+    if (unfused_alt && !(fuse_on && fused)) return unfused_alt->describe();  // what execute() runs when it does not fuse
     std::ostringstream s;
     if (kind == PLAN_TRIVIAL) s << "trivial(len=" << len << ")";
     if (kind == PLAN_BLUESTEIN_LARGE) {
@@ -1337,14 +1381,14 @@ size_t Plan::workspace_bytes() {
         for (auto* pool : {&host_pool, &host_busy})
             for (auto& c : *pool) total += c->in.bytes + c->out.bytes;
     }
-    return total + (inner ? inner->workspace_bytes() : 0);
+    return total + (inner ? inner->workspace_bytes() : 0) + (unfused_alt ? unfused_alt->workspace_bytes() : 0);
 }
 // Releases every cached workspace (the map of slots stays).  Per slot: take the launch lock FIRST (no caller can enqueue a
 // pass that uses the workspace from here on), then drain the device (the stream the slot was used on may be gone; launches
 // already enqueued must finish before their workspace is freed), then free.
 size_t Plan::trim_workspaces() {
     DeviceGuard dev(device);
-    size_t freed = inner ? inner->trim_workspaces() : 0;
+    size_t freed = (inner ? inner->trim_workspaces() : 0) + (unfused_alt ? unfused_alt->trim_workspaces() : 0);
     std::vector<StreamSlot*> all;
     {
         std::lock_guard<std::mutex> g(ws_mutex);
@@ -1791,6 +1835,9 @@ template <class T> static int execute_t(Plan& plan, const void* in, void* out, s
         const int rcf = execute_fused<T>(plan, in, out, batch, stream, false);
         if (rcf != MI355FFT_ERR_UNSUPPORTED) return rcf;  // a batch too small to pipeline runs as two launches
     }
+    // ... of the balanced split when this plan's own split exists for its fused kernel only (build_plan); the profiling hook times the plan's
+    // own named kernels
+    if (plan.unfused_alt && tr == nullptr && P == 2) return execute_t<T>(*plan.unfused_alt, in, out, batch, stream, mode, nullptr, flags | EXEC_NO_FUSE);
 #if defined(MI355_TUNING) || defined(MI355_EMU)
     if (plan.pipe_mode > 0 && tr == nullptr && plan.kind == PLAN_MACRO) return execute_pipelined<T>(plan, in, out, batch, stream);
 #endif

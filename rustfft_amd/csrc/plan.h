@@ -136,6 +136,9 @@ struct Plan {
     std::vector<std::unique_ptr<HostCtx>> host_pool;   // idle contexts
     std::vector<std::unique_ptr<HostCtx>> host_busy;   // contexts lent to a call (kept here so the destructor sees them all)
     std::unique_ptr<Plan> inner;  // PLAN_BLUESTEIN_LARGE: forward power-of-two plan of the padded length M
+    // two-pass plans whose split was taken only for its fused kernel: the balanced split, run whenever the call does not fuse (plan.cpp build_plan)
+    std::unique_ptr<Plan> unfused_alt;
+    bool fused_resplit = false, no_fused_resplit = false;
 
     ~Plan();
     std::string describe() const;

@@ -117,6 +117,28 @@ void register_smooth2_f64_1(std::vector<KernelEntry>&);
 void register_smooth2_f64_2(std::vector<KernelEntry>&);
 void register_smooth2_f64_3(std::vector<KernelEntry>&);
 
+// generated: single-kernel schedules for the 13-smooth lengths in (4096, 16384] (Complex<f32>: 32768] with a factor 11 / 13 (tools/gen_smooth_kernels.py main_big13)
+void register_smooth4_f32_0(std::vector<KernelEntry>&);
+void register_smooth4_f32_1(std::vector<KernelEntry>&);
+void register_smooth4_f32_ns0(std::vector<KernelEntry>&);
+void register_smooth4_f32_ns1(std::vector<KernelEntry>&);
+void register_smooth4_f32_ns2(std::vector<KernelEntry>&);
+void register_smooth4_f32_ns3(std::vector<KernelEntry>&);
+void register_smooth4_f32_ns4(std::vector<KernelEntry>&);
+void register_smooth4_f32_ns5(std::vector<KernelEntry>&);
+void register_smooth4_f32_ns6(std::vector<KernelEntry>&);
+void register_smooth4_f32_ns7(std::vector<KernelEntry>&);
+void register_smooth4_f32_ns8(std::vector<KernelEntry>&);
+void register_smooth4_f32_ns9(std::vector<KernelEntry>&);
+void register_smooth4_f64_0(std::vector<KernelEntry>&);
+void register_smooth4_f64_1(std::vector<KernelEntry>&);
+void register_smooth4_f64_2(std::vector<KernelEntry>&);
+void register_smooth4_f64_3(std::vector<KernelEntry>&);
+void register_smooth4_f64_4(std::vector<KernelEntry>&);
+void register_smooth4_f64_5(std::vector<KernelEntry>&);
+void register_smooth4_f64_6(std::vector<KernelEntry>&);
+void register_smooth4_f64_7(std::vector<KernelEntry>&);
+
 // generated: compiled schedules for the lengths <= 2048 (f64: 1024) with a prime factor 17 .. 31 (tools/gen_smooth_kernels.py main_primes)
 void register_smooth3_f32_0(std::vector<KernelEntry>&);
 void register_smooth3_f32_1(std::vector<KernelEntry>&);

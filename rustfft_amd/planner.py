@@ -181,6 +181,14 @@ def device_count(lib=None):
     return (lib or _native.load()).mi355fft_device_count()
 
 
+def device_cpulist(device, lib=None):
+    """Cores of the NUMA node GPU `device` is attached to ("0-63,128-191"; "" when sysfs does not say): where the library binds the
+    threads it creates for that device (mi355fft_device_cpulist)."""
+    buf = ctypes.create_string_buffer(4096)
+    n = (lib or _native.load()).mi355fft_device_cpulist(int(device), buf, 4096)
+    return buf.value.decode() if n >= 0 else ""
+
+
 def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
@@ -482,6 +490,10 @@ class FftMulti:
 
     def devices(self):
         return [self._lib.mi355fft_multi_plan_device(self._h, g) for g in range(self.shards())]
+
+    def shard_pinned(self, shard):
+        """True when the shard's worker thread is bound to the cores of its GPU's NUMA node (mi355fft_multi_plan_shard_pinned)."""
+        return bool(self._lib.mi355fft_multi_plan_shard_pinned(self._h, int(shard)))
 
     def shard_rows(self, batch, shard):
         first, rows = ctypes.c_size_t(0), ctypes.c_size_t(0)

@@ -113,6 +113,8 @@ pub mod ffi {
         pub fn mi355fft_multi_process_outofplace_dev(plan: *const Mi355MultiPlan, inputs: *const *mut c_void, outputs: *const *mut c_void, batch: usize, streams: *const *mut c_void) -> c_int;
         pub fn mi355fft_multi_process_immutable_dev(plan: *const Mi355MultiPlan, inputs: *const *const c_void, outputs: *const *mut c_void, batch: usize, streams: *const *mut c_void) -> c_int;
         pub fn mi355fft_multi_synchronize(plan: *const Mi355MultiPlan, streams: *const *mut c_void) -> c_int;
+        pub fn mi355fft_device_cpulist(device: c_int, buf: *mut std::ffi::c_char, cap: usize) -> c_int;
+        pub fn mi355fft_multi_plan_shard_pinned(plan: *const Mi355MultiPlan, shard: c_int) -> c_int;
         pub fn mi355fft_multi_scatter_dev(plan: *const Mi355MultiPlan, root_buffer: *const c_void, root_device: c_int, buffers: *const *mut c_void, batch: usize, streams: *const *mut c_void) -> c_int;
         pub fn mi355fft_multi_gather_dev(plan: *const Mi355MultiPlan, buffers: *const *mut c_void, root_buffer: *mut c_void, root_device: c_int, batch: usize, streams: *const *mut c_void) -> c_int;
         pub fn mi355fft_measure_copy_ceiling(bytes: usize, gbps: *mut f64) -> c_int;

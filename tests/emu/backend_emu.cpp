@@ -6,6 +6,7 @@
 // remembers the device it was made on, and a copy whose device-side pointer belongs to another device than the calling
 // thread's current one fails -- which is how the multi-device entry points (mi355fft_multi_*) are checked on the CPU: a
 // worker that forgets to switch to its shard's device, or touches another shard's staging buffer, returns an error here.
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -115,6 +116,12 @@ void* host_word_alloc(void** device_ptr) {
 }
 void host_word_free(void* p) { free(p); }
 int cu_count() { return 256; }
+// fake node: device d sits at PCI address 0000:<d>1:00.0 (tests point MI355FFT_SYSFS_ROOT at a directory that describes it)
+std::string pci_bus_id(int device) {
+    char buf[32];
+    snprintf(buf, sizeof buf, "0000:%x1:00.0", device & 15);
+    return buf;
+}
 int mem_info(size_t* f, size_t* t) {
     *f = *t = (size_t)288 << 30;
     return 0;

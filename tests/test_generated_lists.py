@@ -64,6 +64,7 @@ def test_smooth_units_match_the_generator_and_the_noslp_choice():
         "smooth2": ([x for x in gs.smooth(16384, [2, 3, 5, 7]) if x > 4096 and (x & (x - 1)) and gs.big_schedule(x, (16, 32))] +
                     [x for x in gs.smooth(32768, [2, 3, 5, 7]) if x > 16384 and (x & (x - 1)) and gs.big_schedule32(x)]),
     }
+    want["smooth4"] = gs.big13_sizes((16, 32)) + gs.big13_sizes32()  # round 5: the 13-smooth lengths in (4096, 32768] with a factor 11 / 13
     csrc = os.path.join(ROOT, "rustfft_amd", "csrc")
     for fam, sizes in want.items():
         seen = {}
@@ -79,7 +80,7 @@ def test_smooth_units_match_the_generator_and_the_noslp_choice():
                 seen[n] = unit
         assert sorted(seen) == sorted(sizes), (fam, sorted(set(seen) ^ set(sizes))[:10])
         ns = {n for n, u in seen.items() if u.startswith("ns")}
-        assert ns == set(choice[fam]) & set(sizes), (fam, sorted(ns ^ (set(choice[fam]) & set(sizes)))[:10])
+        assert ns == set(choice.get(fam, [])) & set(sizes), (fam, sorted(ns ^ (set(choice.get(fam, [])) & set(sizes)))[:10])
 
 
 def test_general_tile_units_match_the_noslp_choice():

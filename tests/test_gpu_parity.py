@@ -461,7 +461,8 @@ def test_general_column_tile_passes(planners, oracle, dtype):
 
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_single_kernel_above_4096(planners, oracle, dtype):
-    """2^13 .. 2^15 (f32; 2^14 in f64) and every generated 7-smooth length in (4096, 16384] run as one split-exchange kernel:
+    """2^13 .. 2^15 (f32; 2^14 in f64) and every generated 7-smooth length in (4096, 16384] -- round 5: and every 13-smooth one with a factor
+    11 / 13 (kernels_smooth4_*: 264 lengths in f32, 173 in f64, two general column-tile passes until then) -- run as one split-exchange kernel:
     vs the oracle's plan (Radix4 / RadixN, src/plan.rs:508-607) under the reference tolerance and vs numpy in float64."""
     import glob
     import re
@@ -470,9 +471,9 @@ def test_single_kernel_above_4096(planners, oracle, dtype):
     tag = "f32" if dtype == np.complex64 else "f64"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sizes = [8192, 16384] + ([32768] if dtype == np.complex64 else [])
-    for f in glob.glob(os.path.join(root, "rustfft_amd", "csrc", "kernels_smooth2_%s_*.hip" % tag)):
+    for f in glob.glob(os.path.join(root, "rustfft_amd", "csrc", "kernels_smooth2_%s_*.hip" % tag)) + glob.glob(os.path.join(root, "rustfft_amd", "csrc", "kernels_smooth4_%s_*.hip" % tag)):
         sizes += [int(m) for m in re.findall(r'MI_K1X?\(\w+, \d+, 1, true, (?:\d+, "t1", )?(\d+),', open(f).read())]
-    assert len(sizes) > 100
+    assert len(sizes) > 280 and 5005 in sizes and 13312 in sizes
     for n in sorted(sizes):
         d = n % 2
         fft = planner.plan_fft(n, d)
@@ -495,7 +496,7 @@ def test_runtime_scheduled_kernels(planners, oracle, dtype):
     planner = planners[np.dtype(dtype)]
     import rustfft_amd
 
-    for n in [4368, 4459, 4620, 5005, 20449, 45056]:  # 13-smooth above one workgroup: column-tile passes with 11 / 13 in the tile heights
+    for n in [36608, 40898, 45056] + ([16731, 20449] if dtype == np.complex128 else []):  # 13-smooth above the whole-row kernels (f32: 32768, f64: 16384): column-tile passes with 11 / 13 in the tile heights
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
             assert "k2gfirst" in fft.describe(), (n, fft.describe())
@@ -1174,7 +1175,8 @@ def test_soak_300_mixed_lengths_in_one_process(planners):
 
     import rustfft_amd
 
-    lengths = _lengths_file("general_f32_lengths.txt") + _lengths_file("prime_tile_rader_large_lengths.txt")
+    lengths = _lengths_file("general_f32_lengths.txt") + _lengths_file("prime_tile_rader_large_lengths.txt") + [4875, 45056, 9000, 17325, 4199, 1 << 17, 1 << 22, 3 << 19]
+    lengths = list(dict.fromkeys(lengths))
     assert len(lengths) >= 300 and 603680 in lengths and 1176121 in lengths
     planner = rustfft_amd.FftPlanner(np.complex64)
     x = torch.empty((1 << 30) // 8, dtype=torch.complex64, device="cuda")
@@ -1203,13 +1205,14 @@ def test_soak_300_mixed_lengths_in_one_process(planners):
     print("soak: worst rel L2", worst, "device memory held by 300 plans' tables", lost)
 
 
-@pytest.mark.parametrize("dtype,log2n,batch", [(np.complex64, 20, 64), (np.complex128, 19, 48), (np.complex64, 23, 16)])
+@pytest.mark.parametrize("dtype,log2n,batch", [(np.complex64, 16, 512), (np.complex64, 20, 64), (np.complex128, 19, 48), (np.complex64, 23, 16)])
 def test_fused_giveup_cannot_be_missed_on_the_device(planners, dtype, log2n, batch):
     """VERDICT r4 weak 2 / ADVICE r4: a fused launch whose wait gave up used to return success with wrong data on the `_dev` path.  With the
     wait limit at 0 every dependency that is not already met gives up (include/mi355fft.h mi355fft_plan_set_fused_wait_limit) -- a healthy
     device then produces real give-ups: the sticky word is raised, the NEXT device call on the plan and stream fails without running, the
-    explicit status reports and clears it, host slices come back CORRECT (the rows are re-run as one launch per pass), and with the limit
-    restored the plan is as good as new."""
+    explicit status reports and clears it, host slices come back CORRECT (the rows are re-run as one launch per pass; 2^16 x 512: four
+    chunks of 128 rows, each a fused launch -- the longer rows' 64 MiB chunks hold fewer rows than the ring has slots and run as two
+    launches anyway), and with the limit restored the plan is as good as new."""
     import torch
 
     import rustfft_amd
@@ -1223,7 +1226,12 @@ def test_fused_giveup_cannot_be_missed_on_the_device(planners, dtype, log2n, bat
     x = torch.empty(batch * n, dtype=tdt, device="cuda")
     torch.view_as_real(x).uniform_(-1.0, 1.0)
     want = x.clone()
-    ref.process(want)
+    fft.process(want)  # the fused launch's own result (bit-repeatable; equal to the two-launch plan's up to rounding: other compilation units)
+    assert fft.fused_status() == 0
+    want_two = x.clone()
+    ref.process(want_two)
+    tol = (4e-7 if dtype == np.complex64 else 1e-15) * float(want.abs().max())
+    assert float((want - want_two).abs().max()) <= tol
     fft.set_fused_wait_limit(0)
     gave_up = 0
     for _ in range(5):
@@ -1241,21 +1249,27 @@ def test_fused_giveup_cannot_be_missed_on_the_device(planners, dtype, log2n, bat
             assert torch.equal(torch.view_as_real(y), torch.view_as_real(want))
         fft.fused_status()  # (clears whatever the second call left)
     assert gave_up >= 1, "a wait limit of 0 produced no give-up in five launches: the test does not exercise the path"
-    y = x.clone()
-    fft.process(y)
-    assert fft.fused_status() == 1 and fft.fused_status() == 0  # reported once
+    for _ in range(20):  # (not every launch has a wait that is unmet at its first poll)
+        y = x.clone()
+        fft.process(y)
+        if fft.fused_status() == 1:
+            break
+    else:
+        raise AssertionError("no give-up in twenty launches with a wait limit of 0")
+    assert fft.fused_status() == 0  # reported once
     # host slices: the call succeeds with correct rows although its fused launches gave up
+    # (rows of chunks whose launch gave up come from the two-launch kernels, the others from the fused one: equal up to rounding)
     hx = x.cpu().numpy()
     hwant = want.cpu().numpy()
     a = hx.copy()
     fft.process(a)
-    assert np.array_equal(a, hwant), "in place"
+    assert float(np.abs(a - hwant).max()) <= tol, "in place"
     out = np.empty_like(hx)
     fft.process_immutable_with_scratch(hx, out)
-    assert np.array_equal(out, hwant), "immutable"
+    assert float(np.abs(out - hwant).max()) <= tol, "immutable"
     src = hx.copy()
     fft.process_outofplace_with_scratch(src, out)
-    assert np.array_equal(out, hwant), "out of place"
+    assert float(np.abs(out - hwant).max()) <= tol, "out of place"
     assert fft.fused_status() == 0
     fft.set_fused_wait_limit(1 << 21)
     for _ in range(3):
@@ -1319,16 +1333,15 @@ def test_fused_launch_under_a_second_process(planners):
                     xs.append(x)
                     wants.append(w)
                 y = torch.empty_like(xs[0])
-                exact = log2n != 21 or dtype != np.complex64  # (f32 2^21: the fused kernel's later tile has another shape -> equal up to rounding; compare launch to launch)
+                # the fused kernel is another compilation of the same bodies (f32 2^21: another later tile): equal to the two-launch plan up to
+                # rounding, and bit-identical from launch to launch -- every word of every launch is compared with the first launch's
                 firsts = [None, None]
                 for r in range(200):
                     i = r & 1
                     fft.process_immutable_with_scratch(xs[i], y)
-                    if exact:
-                        assert torch.equal(torch.view_as_real(y), torch.view_as_real(wants[i])), (dtype, log2n, r)
-                    elif firsts[i] is None:
+                    if firsts[i] is None:
                         firsts[i] = y.clone()
-                        assert float((y - wants[i]).abs().max()) <= 4e-7 * float(wants[i].abs().max())
+                        assert float((y - wants[i]).abs().max()) <= (4e-7 if dtype == np.complex64 else 1e-15) * float(wants[i].abs().max()), (dtype, log2n)
                     else:
                         assert torch.equal(torch.view_as_real(y), torch.view_as_real(firsts[i])), (dtype, log2n, r)
                     if r % 50 == 49:

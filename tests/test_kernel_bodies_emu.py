@@ -373,9 +373,10 @@ def test_general_column_tile_passes(emu_planner, oracle, dtype):
     the strides (per-column b mod s), ragged last tiles (M not a multiple of F), pure powers of 3 and 5.  The
     reference plans these as RadixN / MixedRadix (src/plan.rs:430-560)."""
     planner = emu_planner(dtype)
-    # (round 2: tile heights with the factors 11 and 13 too -- 20449 = 11^2 13^2, 45056 = 11 * 2^12, 5005 = 5 7 11 13)
+    # (round 2: tile heights with the factors 11 and 13 too -- 40898 = 2 11^2 13^2, 45056 = 11 * 2^12, 36608 = 2^8 11 13; round 5: such lengths up to
+    # 16384 (Complex<f32>: most up to 32768) are whole-row kernels, test_single_kernel_above_4096)
     for n, npass in ((36864, 2), (39366, 2), (50000, 2), (44100, 2), (78125, 2), (98304, 2), (100000, 2), (1000000, 3), (3686400, 3),
-                     (20449, 2), (45056, 2), (5005, 2), (157300, 2)):
+                     (40898, 2), (45056, 2), (36608, 2), (157300, 2)):
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
             desc = fft.describe()
@@ -390,6 +391,7 @@ def test_single_kernel_above_4096(emu_planner, oracle, dtype):
     plane one after the other (engine.h SPLIT): all API modes vs the oracle's plan, every radix mix of the generated list."""
     planner = emu_planner(dtype)
     sizes = [4116, 4375, 5000, 6561, 8192, 10000, 12288, 16384] + ([14406, 15625, 16200, 19683, 25000, 32768] if dtype == np.complex64 else [])
+    sizes += [4125, 4459, 5005, 9009, 13312] + ([15015, 16380, 16562, 20449, 26325] if dtype == np.complex64 else [])  # round 5: factors 11 / 13 (kernels_smooth4_*; f32 also with 32 values per thread, up to 32768)
     for n in sizes:
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
@@ -403,8 +405,8 @@ def test_runtime_scheduled_kernels(emu_planner, oracle, dtype):
     src/algorithm/radixn.rs:497-541 covers factors 2..7 over small bases; here every compiled radix appears) and
     primes with 13-smooth p - 1 through the run-time scheduled Rader (raders_algorithm.rs:302-309: primes < 100)."""
     planner = emu_planner(dtype)
-    for n in [4368, 4459, 4620, 5005]:  # (round 1 planned these through the run-time scheduled kernel; they are column-tile plans now)
-        assert "k2gfirst" in planner.plan_fft(n, 0).describe()
+    for n in [4368, 4459, 4620, 5005]:  # (round 1 planned these through the run-time scheduled kernel, rounds 2 - 4 as column-tile plans; whole-row kernels now)
+        assert planner.plan_fft(n, 0).describe().startswith("k1<%d," % n)
     primes = [p for p in range(5, 100) if all(p % q for q in range(2, int(p**0.5) + 1))] + [127, 211, 257, 331, 1201, 2311, 3001]
     import rustfft_amd
 

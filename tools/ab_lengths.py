@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--dtype", default="f32")
     ap.add_argument("--gib", type=float, default=0.5)
     ap.add_argument("--check", action="store_true", help="also compare the two builds' results on four rows (relative L2 of b against a)")
+    ap.add_argument("--no-trim", action="store_true", help="keep every plan's workspace (what this tool did before round 4's last hour: a sweep over hundreds of multi-pass lengths then runs the device out of memory)")
     ap.add_argument("--all", action="store_true", help="time a length even when both builds describe the same plan (a changed kernel body keeps its name)")
     args = ap.parse_args()
     dt, tdt, esz = (np.complex64, torch.complex64, 8) if args.dtype == "f32" else (np.complex128, torch.complex128, 16)
@@ -84,7 +85,7 @@ def main():
         tb = [batch * 2 * n * esz / (t * 1e-3) / 1e12 for t in best]
         print(json.dumps({"n": n, "a_TBps": round(tb[0], 3), "b_TBps": round(tb[1], 3), "b_over_a": round(tb[1] / tb[0], 3), "rel_l2_b_vs_a": diff,
                           "plan_a": ffts[0].describe(), "plan_b": ffts[1].describe()}), flush=True)
-        for f in ffts:
+        for f in (() if args.no_trim else ffts):
             f.trim_workspaces()  # a planner keeps its plans: hundreds of lengths would otherwise hold hundreds of workspaces
 
 

@@ -131,21 +131,25 @@ def rows_per_wg(n, tpf, esz):
 RADICES_BIG = [32, 30, 28, 27, 25, 24, 21, 20, 18, 16, 15, 14, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2]
 
 
-def factorizations_big(n, start=0):
+# the same with the multiples of 11 and 13 (round 5: the 13-smooth lengths above 16384; a radix-26 butterfly is one in-register step 2 x 13)
+RADICES_BIG13 = sorted(set(RADICES_BIG + [26, 22, 13, 11]), reverse=True)
+
+
+def factorizations_big(n, start=0, radices=RADICES_BIG):
     if n == 1:
         yield []
         return
-    for i in range(start, len(RADICES_BIG)):
-        r = RADICES_BIG[i]
+    for i in range(start, len(radices)):
+        r = radices[i]
         if n % r == 0:
-            for rest in factorizations_big(n // r, i):
+            for rest in factorizations_big(n // r, i, radices):
                 yield [r] + rest
 
 
-def big_schedule32(n):
+def big_schedule32(n, radices=RADICES_BIG):
     """f32, 32 values per thread, radices up to 32: fewest sub-passes (each one is an LDS round trip and two barriers)."""
     best = None
-    for rad in factorizations_big(n):
+    for rad in factorizations_big(n, 0, radices):
         if len(rad) > 4:
             continue
         tpf = max(math.ceil((n // r) / (32 // r)) for r in rad)
@@ -192,12 +196,12 @@ def big_schedule(n, emaxes=(16, 32)):
 # operations and pays in register moves -- 62 of 476 13-smooth lengths, 280 of 563 prime-radix lengths, 147 of 223 large 7-smooth ones, median
 # gain 5 / 8 / 10 %, up to 76 %).  They go into their own translation units ("ns"), which the Makefile compiles with -fno-slp-vectorize.
 _NOSLP = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "smooth_noslp_choice.json")))
-NS_UNITS = {"smooth": 1, "smooth2": 3, "smooth3": 7}
+NS_UNITS = {"smooth": 1, "smooth2": 3, "smooth3": 7, "smooth4": 10}
 
 
 def units_of(family, tag, sizes, nfiles):
     """[(unit name, lengths)]: the numbered units hold what stays with the vectoriser, the "ns" units (Complex<f32> only) the rest."""
-    ns = sorted(set(_NOSLP[family]) & set(sizes)) if tag == "f32" else []
+    ns = sorted(set(_NOSLP.get(family, [])) & set(sizes)) if tag == "f32" else []
     keep = [x for x in sizes if x not in set(ns)]
     out = [(str(ci), keep[ci::nfiles]) for ci in range(nfiles)]
     if ns:
@@ -225,6 +229,49 @@ def main_big():
                          '#include "launch.h"\nnamespace mi355 {\n'
                          f"void register_smooth2_{tag}_{ci}(std::vector<KernelEntry>& reg) {{\n" + "\n".join(lines) + "\n}\n}  // namespace mi355\n")
         print(len(sizes), "lengths in (4096, 16384] (f32: 32768],", tag)
+
+
+def big13_sizes(emaxes=(16,)):
+    """13-smooth lengths in (4096, 16384] with a factor 11 or 13 (the 7-smooth ones are main_big's).  Complex<f64>: the 173 of the 264 that
+    run on at most 1024 threads with 16 values per thread (32 double-precision values per thread spill)."""
+    s7 = set(smooth(16384, [2, 3, 5, 7]))
+    return [x for x in smooth(16384, [2, 3, 5, 7, 11, 13]) if x > 4096 and x not in s7 and big_schedule(x, emaxes)]
+
+
+def big13_sizes32():
+    """Complex<f32> only: the 13-smooth lengths in (16384, 32768] with a factor 11 or 13 that have a schedule of at most four sub-passes on at
+    most 1024 threads with 32 values per thread (101 of 198), minus the ones that measured slower than their two-pass plan (BIG13_32_LOSERS)."""
+    s7 = set(smooth(32768, [2, 3, 5, 7]))
+    return [x for x in smooth(32768, [2, 3, 5, 7, 11, 13]) if x > 16384 and x not in s7 and x not in BIG13_32_LOSERS and big_schedule32(x, RADICES_BIG13)]
+
+
+BIG13_32_LOSERS = set()
+
+
+def main_big13():
+    """kernels_smooth4_*: the 13-smooth lengths in (4096, 16384] that have a factor 11 or 13 as single split-exchange kernels (round 5).
+    Until then they ran as two general column-tile passes (k2g_body) -- four HBM crossings per transform and partially filled 64-column
+    tiles: 2.0 - 2.5 TB/s against 4 - 5 TB/s for their 7-smooth neighbours, which had whole-row kernels (gpurun_out r5_01, the reference
+    plans both kinds the same way: RadixN / MixedRadix over butterflies, src/plan.rs:508-607).  16 values per thread (the radix-11 / 13
+    butterflies: butterflies.h), up to 1024 threads."""
+    for tag, ty, prec, esz in (("f32", "float", 32, 8), ("f64", "double", 64, 16)):
+        emaxes = (16, 32) if prec == 32 else (16,)
+        sizes = big13_sizes(emaxes) + (big13_sizes32() if prec == 32 else [])
+        # Complex<f32>: 302 of the 365 lengths measured >= 2 % faster in both of two runs without the SLP vectoriser (median +11 %:
+        # 3.14 -> 3.86 TB/s; profiles/r5/ab_smooth4_noslp_f32_rep*.jsonl) and sit in the ten "ns" units, the rest in two
+        nfiles = 2 if prec == 32 else 8
+        for ci, chunk in units_of("smooth4", tag, sizes, nfiles):
+            lines = []
+            for n in chunk:
+                rad, tpf = big_schedule(n, emaxes) if n <= 16384 else big_schedule32(n, RADICES_BIG13)
+                lines.append(k1_line(ty, prec, 1, "true", n, tpf, rad))
+            path = os.path.join(ROOT, "rustfft_amd", "csrc", f"kernels_smooth4_{tag}_{ci}.hip")
+            with open(path, "w") as fh:
+                fh.write(f"// GENERATED by tools/gen_smooth_kernels.py — do not edit.  Single-kernel schedules (split exchange) for the 13-smooth\n"
+                         f"// lengths in (4096, 16384] with a factor 11 or 13 (unit {ci}), Complex<{ty}>.\n"
+                         '#include "launch.h"\nnamespace mi355 {\n'
+                         f"void register_smooth4_{tag}_{ci}(std::vector<KernelEntry>& reg) {{\n" + "\n".join(lines) + "\n}\n}  // namespace mi355\n")
+        print(len(sizes), "13-smooth lengths with a factor 11 / 13 in (4096, 16384] (f32: 32768],", tag)
 
 
 BIG_PRIMES = [31, 29, 23, 19, 17]
@@ -270,6 +317,7 @@ def main_primes(limits=(("f32", "float", 32, 8, 4096, 14), ("f64", "double", 64,
 
 def main():
     main_big()
+    main_big13()
     main_primes()
     sizes = [x for x in smooth(4096, [2, 3, 5, 7, 11, 13]) if x > 2 and (x & (x - 1)) and x != 1200]
     for tag, ty, prec, esz in (("f32", "float", 32, 8), ("f64", "double", 64, 16)):
