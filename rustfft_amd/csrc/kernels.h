@@ -1121,7 +1121,11 @@ MI_HD void rader_rows_body(X& ex, const RaderParams<T>& p, long long block, void
                     x = v[L::XN0 + i];
                 } else {
                     const int t = tid + i * NT;
+#if defined(MI355_NT_PROBE)  // probe build (make tuning-min MINEXTRA=-DMI355_NT_PROBE): the rows loop reads its rows with non-temporal loads
+                    x = ((i + 1) * NT <= P || t < P) ? ld_nt(in + (row * P + t)) : cx<T>{0, 0};
+#else
                     x = ((i + 1) * NT <= P || t < P) ? in[row * P + t] : cx<T>{0, 0};
+#endif
                 }
                 x.im *= sgn;
                 work[reg_to_idx<T>(v[L::PI0 + i])] = x;

@@ -34,8 +34,11 @@ void register_k1_f32(std::vector<KernelEntry>& reg) {
     // 2^13 .. 2^15 in ONE kernel: the real and imaginary planes go through LDS one after the other (split exchange), so a
     // whole 32768-point row fits 132 KB.  Measured on MI355X: 18.0 / 20.8 / 20.3 TFLOP/s (4.6 / 4.8 / 4.3 TB/s) against
     // 10.6 / 12.2 / 12.7 for two column-tile passes.  Variants: the 16-values-per-thread schedules (4.4 - 4.5 TB/s at 8192).
-    MI_K1X(float, 32, 1, true, 1024, "t1", 8192, 256, 8, 32, 32);
-    MI_K1X(float, 32, 1, true, 1024, "t1", 16384, 512, 16, 32, 32);
+    // round 5: 8192 and 16384 read their rows with NON-TEMPORAL loads ("n"; ABL bit 16): +2.8 ... +2.9 % and +3.7 ... +4.0 % in two interleaved
+    // runs (5.39 -> 5.54 and 5.13 -> 5.33 TB/s), bit-identical results; 1024: +0.3 ... +1.9 %, 2048 / 4096 / 32768: -1 ... -6 %; non-temporal
+    // STORES lose everywhere (up to -31 % at 16384): profiles/r5/ab_k1_nt_2p*.jsonl, ab_k1_ntload_confirm_2p*.jsonl
+    MI_K1X(float, 32, 1, true, 1040, "t1n", 8192, 256, 8, 32, 32);
+    MI_K1X(float, 32, 1, true, 1040, "t1n", 16384, 512, 16, 32, 32);
     MI_K1X(float, 32, 1, true, 1024, "t1", 32768, 1024, 32, 32, 32);
     MI_K1V(3, float, 32, 1, false, 8192, 512, 16, 8, 8, 8);
     // tuning: split exchange for the LDS-bound 2^10 .. 2^12 kernels (half the LDS per workgroup: six instead of four per CU)

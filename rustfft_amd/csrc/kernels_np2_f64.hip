@@ -4,8 +4,13 @@
 #include "kernel_lists.h"
 namespace mi355 {
 void register_np2_f64(std::vector<KernelEntry>& reg) {
-    MI_K1(double, 64, 2, false, 1200, 120, 10, 10, 12);
+    // round 5: rows read AND written with non-temporal accesses ("n", ABL bits 16 + 32): 5.48 - 5.62 -> 5.93 - 5.97 TB/s in three interleaved
+    // runs (+6 ... +7 %; loads only: +2 ... +3 %), bit-identical (profiles/r5/ab_c3_nt*.jsonl) -- the one whole-row kernel where the
+    // stores gain too (the Complex<f32> power-of-two rows lose up to 31 % with them)
+    MI_K1X(double, 64, 2, false, 48, "n", 1200, 120, 10, 10, 12);
     // tuning: other orders / tilings of 1200 (tools/ab.py --n 1200 --dtype f64 min:MI355FFT_VARIANT=k)
+    MI_K1ABL(51, 16, double, 64, 2, false, 1200, 120, 10, 10, 12);  // round 5: non-temporal loads (51) / loads and stores (50)
+    MI_K1ABL(50, 48, double, 64, 2, false, 1200, 120, 10, 10, 12);
     MI_K1V(1, double, 64, 2, false, 1200, 120, 12, 10, 10);
     MI_K1V(2, double, 64, 2, false, 1200, 120, 10, 12, 10);
     MI_K1V(3, double, 64, 4, false, 1200, 120, 10, 10, 12);

@@ -1341,7 +1341,8 @@ def test_fused_launch_under_a_second_process(planners):
                     fft.process_immutable_with_scratch(xs[i], y)
                     if firsts[i] is None:
                         firsts[i] = y.clone()
-                        assert float((y - wants[i]).abs().max()) <= (4e-7 if dtype == np.complex64 else 1e-15) * float(wants[i].abs().max()), (dtype, log2n)
+                        # (2^17, 2^18, 2^21 in Complex<f32>: the two-launch plan is the BALANCED split, other tile heights than the fused pair's)
+                        assert float((y - wants[i]).abs().max()) <= (1.5e-6 if dtype == np.complex64 else 4e-15) * float(wants[i].abs().max()), (dtype, log2n)
                     else:
                         assert torch.equal(torch.view_as_real(y), torch.view_as_real(firsts[i])), (dtype, log2n, r)
                     if r % 50 == 49:
