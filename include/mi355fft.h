@@ -282,7 +282,9 @@ int mi355fft_plan_is_fused(const mi355fft_plan* plan);
  * the last report was met in time; also 0 when the plan never ran fused); reporting clears it. */
 int mi355fft_plan_fused_status(const mi355fft_plan* plan, void* stream, unsigned* error_word);
 /* The bound: polls of about half a microsecond before a dependency wait gives up (default 2^21: about a second).  0 makes every wait that is
- * not already satisfied give up -- how the tests exercise the paths above on a healthy device. */
+ * not already satisfied give up -- how the tests exercise the paths above on a healthy device; -1 does the same and, in addition, raises the
+ * word after EVERY fused launch whether or not a wait gave up (a deterministic test hook: at some sizes a healthy device meets every
+ * dependency at the first poll nine launches out of ten). */
 int mi355fft_plan_set_fused_wait_limit(mi355fft_plan* plan, int polls);
 /* Workspace placement (off by default).  Identical multi-pass plans run up to 3.6 % apart depending on which device allocation
  * holds their in-place workspace (profiles/r3/ab_ws_placement.jsonl).  With on = 1, the FIRST in-place call of a (plan, stream)

@@ -555,7 +555,7 @@ int mi355fft_plan_fused_status(const mi355fft_plan* plan, void* stream, unsigned
     return MI355FFT_OK;
 }
 int mi355fft_plan_set_fused_wait_limit(mi355fft_plan* plan, int polls) {
-    if (!plan || polls < 0) return set_err(MI355FFT_ERR_INVALID_ARG, "bad wait limit");
+    if (!plan || polls < -1) return set_err(MI355FFT_ERR_INVALID_ARG, "bad wait limit");
     plan->p.fuse_spin_limit = polls;
     if (plan->p.inner) plan->p.inner->fuse_spin_limit = polls;
     return MI355FFT_OK;

@@ -1724,7 +1724,7 @@ template <class T> static int execute_fused(Plan& plan, const void* in, void* ou
     fp.units = units;
     fp.slot_elems = (long long)slot_elems;
     fp.mode = plan.fuse_mode;
-    fp.spin_limit = plan.fuse_spin_limit;  // x s_sleep(8) ~ 0.5 us each: about a second by default
+    fp.spin_limit = plan.fuse_spin_limit < 0 ? 0 : plan.fuse_spin_limit;  // x s_sleep(8) ~ 0.5 us each: about a second by default
     const long long grid = k2f_grid((long long)steps, t0, t1, lag);
     if (grid > kMaxGrid) return grid_too_large(0, k, grid, batch);
     // ticket and dependency counters start at zero for every launch; the error word is NOT part of the block (PipeState::err_host)
@@ -1733,8 +1733,11 @@ template <class T> static int execute_fused(Plan& plan, const void* in, void* ou
     if (backend::check_launch())
         return fail_detail(MI355FFT_ERR_HIP, "fused launch (%s: grid %lld x %d threads, %zu bytes of LDS, %zu steps, lag %d, %d ring slots) failed: %s", k.name, grid, k.threads,
                            k.lds_bytes, steps, lag, ns, backend::last_error().c_str());
+    // test hooks: what a tile whose wait gave up leaves behind, on EVERY fused launch (a limit of 0 only produces the give-ups that really
+    // occur, which at some sizes is one launch in ten) -- mi355fft_plan_set_fused_wait_limit(plan, -1); the emulator: MI355FFT_FUSED_GIVEUP
+    if (plan.fuse_spin_limit < 0) *pp.err_host = 1u;
 #if defined(MI355_EMU)
-    if (env_int("MI355FFT_FUSED_GIVEUP")) *pp.err_host = 1u;  // tests: what a tile whose wait gave up leaves behind
+    if (env_int("MI355FFT_FUSED_GIVEUP")) *pp.err_host = 1u;
 #endif
     return MI355FFT_OK;
 }

@@ -28,11 +28,27 @@ except OSError:
 _TWL32_EXCLUDE, _TWL64_INCLUDE = set(_TWL["f32_exclude"]), set(_TWL["f64_include"])
 
 
+# Non-temporal row accesses (kernels.h k1_body ABL bits 16 / 32; kernel name suffix "n" = loads, "nn" = loads + stores) -- a per-length measured
+# choice, round 5: every compiled length above 512, shipped build against builds with the hint everywhere (tools/r5/build_smooth_nt.sh), two
+# one-process runs (profiles/r5/ab_smooth_nt{16,48}_{f32,f64}_rep{1,2}.jsonl).  The median over all lengths is 1.00 (loads) / 0.93 (both) --
+# short rows lose 20 %, long rows gain -- so only the lengths that gain >= 2.5 % (loads) / >= 3 % (both, and more than loads alone) in BOTH runs
+# are listed: f32 404 + 27 lengths (median +3.9 % / +5.7 %), f64 159 + 61 (+3.9 % / +5.9 %).
+try:
+    _NT = _json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "smooth_nt_choice.json")))
+except OSError:
+    _NT = {}
+_NT_LOADS = {32: set(_NT.get("f32_loads", [])), 64: set(_NT.get("f64_loads", []))}
+_NT_BOTH = {32: set(_NT.get("f32_both", [])), 64: set(_NT.get("f64_both", []))}
+
+
 def k1_line(ty, prec, f, split, n, tpf, rad):
     staged = len(rad) >= 2 and ((prec == 32 and n not in _TWL32_EXCLUDE) or (prec == 64 and n in _TWL64_INCLUDE))
     args = f"{n}, {tpf}, {', '.join(map(str, rad))}"
+    nt, suf = (48, "nn") if n in _NT_BOTH[prec] else (16, "n") if n in _NT_LOADS[prec] else (0, "")
     if staged:
-        return f'    MI_K1X({ty}, {prec}, {f}, {split}, 1024, "t1", {args});'
+        return f'    MI_K1X({ty}, {prec}, {f}, {split}, {1024 | nt}, "t1{suf}", {args});'
+    if nt:
+        return f'    MI_K1X({ty}, {prec}, {f}, {split}, {nt}, "{suf}", {args});'
     return f"    MI_K1({ty}, {prec}, {f}, {split}, {args});"
 
 RADICES = [16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2]
