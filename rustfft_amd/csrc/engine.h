@@ -354,6 +354,22 @@ template <class L> struct SlotDst {
 template <class L> MI_HD SlotDst<L> slot_dst(L l) { return SlotDst<L>{l}; }
 template <class D> struct is_slot_dst : std::false_type {};
 template <class L> struct is_slot_dst<SlotDst<L>> : std::true_type {};
+// The same two destinations with a PREFETCH hook: pre(f, u, v) runs in front of the last sub-pass's arithmetic, so table entries the
+// destination (or the transform that takes the registers over) multiplies with are in flight while the last butterflies compute
+// (round 5: the Bluestein bodies' spectrum multiplier and output chirp, which were fetched right when they were needed)
+template <class P> struct KeepInRegsPre {
+    P pre;
+};
+template <class L, class P> struct SlotDstPre {
+    L fn;
+    P pre;
+};
+template <class L, class P> struct is_slot_dst<SlotDstPre<L, P>> : std::true_type {};
+template <class D> struct is_keep_in_regs : std::is_same<D, KeepInRegs> {};
+template <class P> struct is_keep_in_regs<KeepInRegsPre<P>> : std::true_type {};
+template <class D> struct has_pre : std::false_type {};
+template <class P> struct has_pre<KeepInRegsPre<P>> : std::true_type {};
+template <class L, class P> struct has_pre<SlotDstPre<L, P>> : std::true_type {};
 
 template <class S, int P, Map MIN, Map MOUT> constexpr Map pass_map() {
     return P == 0 ? MIN : (P == S::NP - 1 ? MOUT : MAP_EF);
@@ -419,8 +435,18 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
     ex.for_threads([&](int tid, cx<T>* v) {
         int f, u;
         map_tid<MP, F, S::TPF>(tid, f, u);
-        if constexpr (!(ABL & 4)) compute_pass<T, S, P, TWREG>(v, u, twp);
-        if constexpr (LAST && std::is_same<DST, KeepInRegs>::value) {
+        if constexpr (LAST && has_pre<DST>::value) dst.pre(f, u, v);
+        // (a sub-pass whose table is staged in LDS reads it there; the others take their factors from the registers when TWREG >= 0)
+        if constexpr (!(ABL & 4)) compute_pass<T, S, P, (((TWL >> P) & 1) != 0 ? -1 : TWREG)>(v, u, twp);
+        if constexpr (TWSTAGE && TWREG >= 0 && !LAST && ((TWL >> (P + 1)) & 1) == 0) {
+            // the NEXT sub-pass's factors, fetched a whole exchange (scatter, barrier, gather, barrier) ahead of their use: the table look-up's
+            // latency -- L2 under load: about a microsecond -- is off the row's critical path (round 5: the Bluestein bodies, whose tables are too
+            // large for LDS or a rows loop; the registers are live from here to the next compute_pass only)
+            int f2, u2;
+            map_tid<pass_map<S, P + 1, MIN, MOUT>(), F, S::TPF>(tid, f2, u2);
+            preload_twiddles_pass<T, S, P + 1, TWREG>(v, u2, tw);
+        }
+        if constexpr (LAST && is_keep_in_regs<DST>::value) {
         } else if constexpr (LAST) {
             static_for<0, BPT>([&](auto M_) {
                 constexpr int m = M_;
@@ -455,7 +481,6 @@ MI_HD void wg_fft_stage(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC& 
                 int f, u;
                 map_tid<MQ, F, S::TPF>(tid, f, u);
                 lds_gather<T, S, P + 1, 0>(v, u, (const cx<T>*)lds_raw + f * S::template pitch_for<PM>());
-                if constexpr (TWSTAGE && TWREG >= 0) preload_twiddles_pass<T, S, P + 1, TWREG>(v, u, tw);
             });
             ex.barrier();
         } else {
@@ -514,7 +539,7 @@ template <class T, class S, int F, Map MIN, Map MOUT, bool SPLIT, bool SRC_IN_LD
 MI_HD void wg_fft(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC src, DST dst) {
     static_assert(S::valid(), "radices must multiply to N");
     static_assert(MIN != MAP_FFP || (pair_fusable<S>() && !SRC_IN_LDS && TWREG < 0 && sizeof(T) == 4), "the paired map is the pair-fused path");
-    static_assert(TWL == 0 || (twl_valid<S>(TWL) && !SRC_IN_LDS && TWREG < 0 && MIN != MAP_FFP && S::NP >= 2), "staged tables: plain transforms whose first exchange publishes the copy");
+    static_assert(TWL == 0 || (twl_valid<S>(TWL) && !SRC_IN_LDS && (TWREG < 0 || TWSTAGE) && MIN != MAP_FFP && S::NP >= 2), "staged tables: plain transforms whose first exchange publishes the copy");
     constexpr int R0 = S::R[0], NB0 = S::nb(0), BPT0 = S::bpt(0);
     constexpr int TWN = twl_total<S>(TWL), NT = F * S::TPF, TWPT = (TWN + NT - 1) / NT, TWSRC = S::tw_offset(twl_first<S>(TWL));
     cx<T>* twl = (cx<T>*)((char*)lds_raw + align16(lds_bytes<T, S, F, SPLIT, PM>()) + TWLOFF);
@@ -548,6 +573,11 @@ MI_HD void wg_fft(X& ex, void* lds_raw, const cx<T>* MI_RESTRICT tw, SRC src, DS
                 const int e = tid + i * NT;
                 if ((i + 1) * NT <= TWN || e < TWN) twl[e] = twr[i];
             });
+        }
+        if constexpr (TWSTAGE && TWREG >= 0 && S::NP > 1 && MIN != MAP_FFP && ((TWL >> 1) & 1) == 0) {  // sub-pass 1's factors ride behind the row loads
+            int f1, u1;
+            map_tid<pass_map<S, 1, MIN, MOUT>(), F, S::TPF>(tid, f1, u1);
+            preload_twiddles_pass<T, S, 1, TWREG>(v, u1, tw);
         }
     });
     if constexpr (SRC_IN_LDS) ex.barrier();

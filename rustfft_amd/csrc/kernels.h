@@ -631,7 +631,8 @@ template <class T, class S, int F> constexpr size_t k2r_lds_bytes() { return (si
 // registers of the thread that needs exactly those values as inputs of its first radix-R butterflies, so the spectrum
 // multiply conj(X bf) happens in registers and the intermediate spectrum never goes through LDS (round 1 staged it in a
 // natural-order LDS row: one more write + read of M elements and one more barrier per row).
-template <class T, class S2> struct BluesteinRegSrc {
+// BFREG >= 0: the multiplier entries were fetched into v[BFREG + slot] in front of the first transform's last sub-pass (bluestein_body PF bit 2)
+template <class T, class S2, int BFREG = -1> struct BluesteinRegSrc {
     static constexpr bool kLoadsAll = true;
     const cx<T>* MI_RESTRICT bf;
     template <class SS> MI_HD void load_all(int, int u, cx<T>* v) const {
@@ -643,7 +644,10 @@ template <class T, class S2> struct BluesteinRegSrc {
             if ((m + 1) * S2::TPF <= NB || b < NB) {
                 static_for<0, R>([&](auto K_) {
                     constexpr int k = K_;
-                    v[m * R + k] = cconj(v[m * R + k] * bf[(unsigned)(b + k * NB)]);
+                    if constexpr (BFREG >= 0)
+                        v[m * R + k] = cconj(v[m * R + k] * v[BFREG + m * R + k]);
+                    else
+                        v[m * R + k] = cconj(v[m * R + k] * bf[(unsigned)(b + k * NB)]);
                 });
             }
         });
@@ -656,13 +660,32 @@ template <class T, class S2> struct BluesteinRegSrc {
 // its own region behind the exchange buffer; schedules with at least three sub-passes only (with two, sub-pass 1 is the last one
 // and its table would be the big one)
 template <class S> constexpr bool bluestein_tw1_ok() { return S::NP >= 3; }
-template <class T, class S, int F, bool SPLIT, bool TW1> constexpr size_t bluestein_lds_bytes() {
+// which sub-pass tables of both transforms are staged in LDS: TW1 = sub-pass 1; PF bit 1 (round 5, tuning): every sub-pass but the last (the last
+// one's table is the big one: (R - 1) N / R entries)
+template <class S, bool TW1, int PF> constexpr int bluestein_twl_mask() {
+    if (!bluestein_tw1_ok<S>()) return 0;
+    if ((PF & 2) != 0) return S::NP >= 4 ? (twl_all(S::NP) & ~(1 << (S::NP - 1))) : 2;
+    return TW1 ? 2 : 0;
+}
+template <class T, class S, int F, bool SPLIT, bool TW1, int PF = 0> constexpr size_t bluestein_lds_bytes() {
     using S2 = typename reversed_sched<S>::type;
     const size_t ex = (size_t)F * (S::pitch() > S2::pitch() ? S::pitch() : S2::pitch()) * (SPLIT ? sizeof(T) : sizeof(cx<T>));
-    if (!(TW1 && bluestein_tw1_ok<S>())) return ex;
-    return align16(ex) + align16((size_t)tw_pass_entries<S>(1) * sizeof(cx<T>)) + (size_t)tw_pass_entries<S2>(1) * sizeof(cx<T>);
+    constexpr int MASK = bluestein_twl_mask<S, TW1, PF>();
+    if (MASK == 0) return ex;
+    return align16(ex) + align16((size_t)twl_total<S>(MASK) * sizeof(cx<T>)) + (size_t)twl_total<S2>(MASK) * sizeof(cx<T>);
 }
-template <class T, class S, int F, bool SPLIT = false, bool TW1 = false, class X>
+// PF (tuning so far, round 5) bit 0: the twiddle factors of the sub-passes whose tables are NOT staged in LDS are fetched one exchange ahead of
+// their use into registers behind the data (engine.h TWSTAGE) instead of right after the barrier that precedes the sub-pass; bit 1: every
+// sub-pass table but the last one's staged in LDS (bluestein_twl_mask).
+// bit 2: the spectrum multiplier bf[] of a thread's hand-over values is fetched in FRONT of the first transform's last sub-pass (into registers
+// behind the twiddle block) instead of right when the second transform starts; bit 3: the same for the output chirp of the second transform's
+// last sub-pass.
+template <class S, int PF> constexpr int bluestein_twregs() {
+    using S2 = typename reversed_sched<S>::type;
+    return (PF & 1) ? (twreg_count<S>() > twreg_count<S2>() ? twreg_count<S>() : twreg_count<S2>()) : 0;
+}
+template <class S, int PF> constexpr int bluestein_regs() { return S::emax() + bluestein_twregs<S, PF>() + ((PF & 12) ? S::emax() : 0); }
+template <class T, class S, int F, bool SPLIT = false, bool TW1 = false, int PF = 0, class X>
 MI_HD void bluestein_body(X& ex, const BluesteinParams<T>& p, long long block, void* lds) {
     using S2 = typename reversed_sched<S>::type;
     static_assert(S2::R[0] == S::R[S::NP - 1] && S2::nb(0) == S::nb(S::NP - 1) && S2::bpt(0) == S::bpt(S::NP - 1), "register hand-over");
@@ -683,11 +706,32 @@ MI_HD void bluestein_body(X& ex, const BluesteinParams<T>& p, long long block, v
         return cx<T>{0, 0};
     };
     // both transforms share one exchange buffer of max(pitch) entries per row; the staged tables sit behind it
-    constexpr bool STG = TW1 && bluestein_tw1_ok<S>();
+    constexpr int MASK = bluestein_twl_mask<S, TW1, PF>();
+    constexpr bool STG = MASK != 0;
+    constexpr int TWR = (PF & 1) ? S::emax() : -1;
     constexpr size_t EXB = (size_t)F * (S::pitch() > S2::pitch() ? S::pitch() : S2::pitch()) * (SPLIT ? sizeof(T) : sizeof(cx<T>));
     constexpr int OFF1 = STG ? (int)(align16(EXB) - align16(lds_bytes<T, S, F, SPLIT>())) : 0;
-    constexpr int OFF2 = STG ? (int)(align16(EXB) + align16((size_t)tw_pass_entries<S>(1) * sizeof(cx<T>)) - align16(lds_bytes<T, S2, F, SPLIT>())) : 0;
-    wg_fft<T, S, F, MAP_EF, MAP_EF, SPLIT, false, 1, 0, -1, false, (STG ? 2 : 0), OFF1>(ex, lds, p.tw, elem_src(src1), KeepInRegs{});
+    constexpr int OFF2 = STG ? (int)(align16(EXB) + align16((size_t)twl_total<S>(MASK) * sizeof(cx<T>)) - align16(lds_bytes<T, S2, F, SPLIT>())) : 0;
+    // one spare register block behind data and twiddles: the multiplier entries, later the output chirp (the multiplier is dead by then)
+    constexpr int XREG = S::emax() + bluestein_twregs<S, PF>();
+    const cx<T>* MI_RESTRICT bfp = p.bf;
+    auto pre1 = [=](int, int u, cx<T>* v) {  // geometry of the first transform's LAST sub-pass = the second one's first
+        constexpr int LP = S::NP - 1, R = S::R[LP], NB = S::nb(LP), BPT = S::bpt(LP);
+        static_for<0, BPT>([&](auto M_) {
+            constexpr int m = M_;
+            const int b = u + m * S::TPF;
+            if ((m + 1) * S::TPF <= NB || b < NB) {
+                static_for<0, R>([&](auto K_) {
+                    constexpr int k = K_;
+                    v[XREG + m * R + k] = bfp[(unsigned)(b + k * NB)];
+                });
+            }
+        });
+    };
+    if constexpr ((PF & 4) != 0)
+        wg_fft<T, S, F, MAP_EF, MAP_EF, SPLIT, false, 1, 0, TWR, (PF & 1) != 0, MASK, OFF1>(ex, lds, p.tw, elem_src(src1), KeepInRegsPre<decltype(pre1)>{pre1});
+    else
+        wg_fft<T, S, F, MAP_EF, MAP_EF, SPLIT, false, 1, 0, TWR, (PF & 1) != 0, MASK, OFF1>(ex, lds, p.tw, elem_src(src1), KeepInRegs{});
     // (the engine's barrier after the last gather of the first transform already orders it before the second one's scatters)
     auto dst2 = [=](int f, int j, cx<T> v) {
         if (f < rows && j < n) {
@@ -696,7 +740,34 @@ MI_HD void bluestein_body(X& ex, const BluesteinParams<T>& p, long long block, v
             out[(unsigned)(f * n + j)] = y;
         }
     };
-    wg_fft<T, S2, F, MAP_EF, MAP_EF, SPLIT, false, 1, 0, -1, false, (STG ? 2 : 0), OFF2>(ex, lds, p.tw2, BluesteinRegSrc<T, S2>{p.bf}, dst2);
+    auto dst2s = [=](int f, int j, cx<T> val, auto I_, cx<T>* v) {
+        if (f < rows && j < n) {
+            cx<T> y = cconj(val) * v[XREG + decltype(I_)::value];
+            y.im *= sgn;
+            out[(unsigned)(f * n + j)] = y;
+        }
+    };
+    auto pre2 = [=](int, int u, cx<T>* v) {  // output chirp of the second transform's last sub-pass: element base + k stride of butterfly b
+        constexpr int LP = S2::NP - 1, R = S2::R[LP], NB = S2::nb(LP), ST = S2::stride(LP), BPT = S2::bpt(LP);
+        static_for<0, BPT>([&](auto M_) {
+            constexpr int m = M_;
+            const int b = u + m * S2::TPF;
+            if ((m + 1) * S2::TPF <= NB || b < NB) {
+                const int base = (b / ST) * (ST * R) + (b % ST);
+                static_for<0, R>([&](auto K_) {
+                    constexpr int k = K_;
+                    const int j = base + k * ST;
+                    v[XREG + m * R + k] = chirp[(unsigned)(j < n ? j : 0)];
+                });
+            }
+        });
+    };
+    constexpr int BFR = (PF & 4) ? XREG : -1;
+    if constexpr ((PF & 8) != 0)
+        wg_fft<T, S2, F, MAP_EF, MAP_EF, SPLIT, false, 1, 0, TWR, (PF & 1) != 0, MASK, OFF2>(ex, lds, p.tw2, BluesteinRegSrc<T, S2, BFR>{p.bf},
+                                                                                                 SlotDstPre<decltype(dst2s), decltype(pre2)>{dst2s, pre2});
+    else
+        wg_fft<T, S2, F, MAP_EF, MAP_EF, SPLIT, false, 1, 0, TWR, (PF & 1) != 0, MASK, OFF2>(ex, lds, p.tw2, BluesteinRegSrc<T, S2, BFR>{p.bf}, dst2);
 }
 
 // ---- run-time scheduled batched transform (13-smooth lengths) ------------------------------------------------

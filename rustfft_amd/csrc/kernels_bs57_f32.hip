@@ -32,5 +32,22 @@ void register_bs57_f32(std::vector<KernelEntry>& reg) {
     MI_BSSV(1, float, 32, 1, 10240, 512, 32, 20, 16);
     MI_BSSV(4, float, 32, 1, 14336, 1024, 14, 16, 8, 8);  // tuning 4 / 5: 14336 in four lighter sub-passes instead of 32 x 28 x 16
     MI_BSSV(5, float, 32, 1, 14336, 896, 16, 14, 8, 8);
+    // round 5, tuning 70 / 71 / 72: the shipped body of each inner length (bs_tw1 / bs_pf) + the spectrum multiplier fetched in front of the first
+    // transform's last sub-pass (70), + the output chirp in front of the second one's (71), the chirp alone (72)
+    MI_BSPV(70, 20, float, 32, 1, 1280, 128, 10, 8, 16);
+    MI_BSPV(71, 28, float, 32, 1, 1280, 128, 10, 8, 16);
+    MI_BSPV(72, 24, float, 32, 1, 1280, 128, 10, 8, 16);
+    MI_BSPV(70, 20, float, 32, 1, 2560, 256, 10, 16, 16);
+    MI_BSPV(71, 28, float, 32, 1, 2560, 256, 10, 16, 16);
+    MI_BSPV(72, 24, float, 32, 1, 2560, 256, 10, 16, 16);
+    MI_BSPV(70, 5, float, 32, 1, 3584, 256, 14, 16, 16);
+    MI_BSPV(71, 13, float, 32, 1, 3584, 256, 14, 16, 16);
+    MI_BSPV(72, 9, float, 32, 1, 3584, 256, 14, 16, 16);
+    MI_BSPV(70, 20, float, 32, 1, 5120, 512, 10, 8, 8, 8);
+    MI_BSPV(71, 28, float, 32, 1, 5120, 512, 10, 8, 8, 8);
+    MI_BSPV(72, 24, float, 32, 1, 5120, 512, 10, 8, 8, 8);
+    MI_BSPV(70, 20, float, 32, 1, 7168, 512, 16, 16, 28);
+    MI_BSPV(71, 28, float, 32, 1, 7168, 512, 16, 16, 28);
+    MI_BSPV(72, 24, float, 32, 1, 7168, 512, 16, 16, 28);
 }
 }  // namespace mi355

@@ -20,5 +20,23 @@ void register_bs57_f64(std::vector<KernelEntry>& reg) {
     MI_BSV(1, double, 64, 1, 3584, 256, 16, 16, 14);  // tuning: the largest-first order
     MI_BSV(1, double, 64, 1, 5120, 512, 16, 16, 20);  // tuning: the schedules these replaced
     MI_BSSV(1, double, 64, 1, 10240, 640, 16, 16, 10, 4);
+    // round 5, tuning 60 .. 63 (Complex<f64>): sub-pass factors fetched one exchange ahead (60), every table but the last staged in LDS (61), both (62),
+    // sub-pass 1 staged + the others fetched ahead (63) -- kernels.h bluestein_body PF
+    MI_BSPV(60, 1, double, 64, 1, 2560, 256, 10, 16, 16);
+    MI_BSPV(61, 2, double, 64, 1, 2560, 256, 10, 16, 16);
+    MI_BSPV(62, 3, double, 64, 1, 2560, 256, 10, 16, 16);
+    MI_BSPV(63, 17, double, 64, 1, 2560, 256, 10, 16, 16);
+    MI_BSPV(60, 1, double, 64, 1, 3584, 256, 14, 16, 16);
+    MI_BSPV(61, 2, double, 64, 1, 3584, 256, 14, 16, 16);
+    MI_BSPV(62, 3, double, 64, 1, 3584, 256, 14, 16, 16);
+    MI_BSPV(63, 17, double, 64, 1, 3584, 256, 14, 16, 16);
+    MI_BSPV(60, 1, double, 64, 1, 5120, 640, 8, 8, 8, 10);
+    MI_BSPV(61, 2, double, 64, 1, 5120, 640, 8, 8, 8, 10);
+    MI_BSPV(62, 3, double, 64, 1, 5120, 640, 8, 8, 8, 10);
+    MI_BSPV(63, 17, double, 64, 1, 5120, 640, 8, 8, 8, 10);
+    MI_BSPV(60, 1, double, 64, 1, 7168, 512, 16, 16, 28);
+    MI_BSPV(61, 2, double, 64, 1, 7168, 512, 16, 16, 28);
+    MI_BSPV(62, 3, double, 64, 1, 7168, 512, 16, 16, 28);
+    MI_BSPV(63, 17, double, 64, 1, 7168, 512, 16, 16, 28);
 }
 }  // namespace mi355

@@ -24,5 +24,25 @@ void register_bs_f32(std::vector<KernelEntry>& reg) {
     MI_BSS(float, 32, 1, 16384, 1024, 8, 8, 16, 16);  // 111.8 against 125.0 for 16 x 32 x 32 on 512 threads
     MI_BS2(float, 32, 1, true, 24576, 1024, 32, 32, 24);
     MI_BS2(float, 32, 1, true, 32768, 1024, 32, 32, 32);
+    // round 5, tuning 70 / 71 / 72: the shipped body of each inner length (bs_tw1 / bs_pf) + the spectrum multiplier fetched in front of the first
+    // transform's last sub-pass (70), + the output chirp in front of the second one's (71), the chirp alone (72)
+    MI_BSPV(70, 20, float, 32, 1, 1024, 128, 8, 8, 16);
+    MI_BSPV(71, 28, float, 32, 1, 1024, 128, 8, 8, 16);
+    MI_BSPV(72, 24, float, 32, 1, 1024, 128, 8, 8, 16);
+    MI_BSPV(70, 20, float, 32, 1, 1536, 256, 6, 16, 16);
+    MI_BSPV(71, 28, float, 32, 1, 1536, 256, 6, 16, 16);
+    MI_BSPV(72, 24, float, 32, 1, 1536, 256, 6, 16, 16);
+    MI_BSPV(70, 21, float, 32, 1, 3072, 256, 12, 16, 16);
+    MI_BSPV(71, 29, float, 32, 1, 3072, 256, 12, 16, 16);
+    MI_BSPV(72, 25, float, 32, 1, 3072, 256, 12, 16, 16);
+    MI_BSPV(70, 20, float, 32, 1, 4096, 512, 8, 8, 8, 8);
+    MI_BSPV(71, 28, float, 32, 1, 4096, 512, 8, 8, 8, 8);
+    MI_BSPV(72, 24, float, 32, 1, 4096, 512, 8, 8, 8, 8);
+    MI_BSPV(70, 7, float, 32, 1, 6144, 512, 6, 8, 8, 16);
+    MI_BSPV(71, 15, float, 32, 1, 6144, 512, 6, 8, 8, 16);
+    MI_BSPV(72, 11, float, 32, 1, 6144, 512, 6, 8, 8, 16);
+    MI_BSPV(70, 7, float, 32, 1, 8192, 512, 8, 8, 8, 16);
+    MI_BSPV(71, 15, float, 32, 1, 8192, 512, 8, 8, 8, 16);
+    MI_BSPV(72, 11, float, 32, 1, 8192, 512, 8, 8, 8, 16);
 }
 }  // namespace mi355

@@ -82,5 +82,10 @@ void register_np2_f32(std::vector<KernelEntry>& reg) {
     reg.push_back(make_pointwise<float>(32));
     reg.push_back(make_dyn_k1<float>(32));
     reg.push_back(make_dyn_rader<float>(32));
+    // round 5, tuning 70 / 71 / 72: the shipped body of each inner length (bs_tw1 / bs_pf) + the spectrum multiplier fetched in front of the first
+    // transform's last sub-pass (70), + the output chirp in front of the second one's (71), the chirp alone (72)
+    MI_BSPV(70, 5, float, 32, 1, 2048, 128, 8, 16, 16);
+    MI_BSPV(71, 13, float, 32, 1, 2048, 128, 8, 16, 16);
+    MI_BSPV(72, 9, float, 32, 1, 2048, 128, 8, 16, 16);
 }
 }  // namespace mi355

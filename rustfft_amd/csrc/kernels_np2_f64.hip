@@ -54,5 +54,27 @@ void register_np2_f64(std::vector<KernelEntry>& reg) {
     reg.push_back(make_pointwise<double>(64));
     reg.push_back(make_dyn_k1<double>(64));
     reg.push_back(make_dyn_rader<double>(64));
+    // round 5, tuning 60 .. 63 (Complex<f64>): sub-pass factors fetched one exchange ahead (60), every table but the last staged in LDS (61), both (62),
+    // sub-pass 1 staged + the others fetched ahead (63) -- kernels.h bluestein_body PF
+    MI_BSPV(60, 1, double, 64, 2, 2048, 128, 16, 16, 8);
+    MI_BSPV(61, 2, double, 64, 2, 2048, 128, 16, 16, 8);
+    MI_BSPV(62, 3, double, 64, 2, 2048, 128, 16, 16, 8);
+    MI_BSPV(63, 17, double, 64, 2, 2048, 128, 16, 16, 8);
+    MI_BSPV(60, 1, double, 64, 1, 3072, 256, 12, 16, 16);
+    MI_BSPV(61, 2, double, 64, 1, 3072, 256, 12, 16, 16);
+    MI_BSPV(62, 3, double, 64, 1, 3072, 256, 12, 16, 16);
+    MI_BSPV(63, 17, double, 64, 1, 3072, 256, 12, 16, 16);
+    MI_BSPV(60, 1, double, 64, 1, 4096, 512, 8, 8, 8, 8);
+    MI_BSPV(61, 2, double, 64, 1, 4096, 512, 8, 8, 8, 8);
+    MI_BSPV(62, 3, double, 64, 1, 4096, 512, 8, 8, 8, 8);
+    MI_BSPV(63, 17, double, 64, 1, 4096, 512, 8, 8, 8, 8);
+    MI_BSPV(60, 1, double, 64, 1, 6144, 512, 16, 16, 24);
+    MI_BSPV(61, 2, double, 64, 1, 6144, 512, 16, 16, 24);
+    MI_BSPV(62, 3, double, 64, 1, 6144, 512, 16, 16, 24);
+    MI_BSPV(63, 17, double, 64, 1, 6144, 512, 16, 16, 24);
+    MI_BSPV(60, 1, double, 64, 1, 8192, 512, 16, 8, 8, 8);
+    MI_BSPV(61, 2, double, 64, 1, 8192, 512, 16, 8, 8, 8);
+    MI_BSPV(62, 3, double, 64, 1, 8192, 512, 16, 8, 8, 8);
+    MI_BSPV(63, 17, double, 64, 1, 8192, 512, 16, 8, 8, 8);
 }
 }  // namespace mi355

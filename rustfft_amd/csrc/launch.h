@@ -3,6 +3,7 @@
 // which checks all index arithmetic of the kernel bodies without a GPU.
 #pragma once
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "kernels.h"
@@ -291,11 +292,11 @@ KernelEntry make_k2f(int prec, const char* name, const char* part0, const char* 
     };
     return e;
 }
-template <class T, class S, int F, bool SPLIT = false, bool TW1 = false>
+template <class T, class S, int F, bool SPLIT = false, bool TW1 = false, int PF = 0>
 __global__ __launch_bounds__(F* S::TPF) void bluestein_kernel(BluesteinParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    DevExec<T, regs_needed<S, false>()> ex;
-    bluestein_body<T, S, F, SPLIT, TW1>(ex, p, (long long)blockIdx.x, smem);
+    DevExec<T, bluestein_regs<S, PF>()> ex;
+    bluestein_body<T, S, F, SPLIT, TW1, PF>(ex, p, (long long)blockIdx.x, smem);
 }
 template <class T, class S, int F, int MODE>
 // MODE 2: rows loop with next-row prefetch (>= 3 waves per SIMD in f32); MODE 3: without the prefetch; MODE 4: as MODE 2 for the
@@ -328,8 +329,8 @@ template <class T> KernelEntry make_pointwise(int prec) {
     e.prepare = []() -> int { return 0; };
     return e;
 }
-template <class T, class S, int F, bool SPLIT = false, bool TW1 = false> constexpr size_t bluestein_lds() {
-    return bluestein_lds_bytes<T, S, F, SPLIT, TW1>();  // exchange buffer of both schedules (+ the staged tables)
+template <class T, class S, int F, bool SPLIT = false, bool TW1 = false, int PF = 0> constexpr size_t bluestein_lds() {
+    return bluestein_lds_bytes<T, S, F, SPLIT, TW1, PF>();  // exchange buffer of both schedules (+ the staged tables)
 }
 template <class T, class S, int F, int MODE> constexpr size_t rader_lds() {
     if (rader_rows_mode(MODE)) return (size_t)RaderRows<S, MODE == 6>::SLOTS * sizeof(cx<T>);  // one row at a time
@@ -337,7 +338,7 @@ template <class T, class S, int F, int MODE> constexpr size_t rader_lds() {
     return (size_t)F * (S::pitch() + (MODE >= 1 ? 0 : S::N + 1)) * sizeof(cx<T>);
 }
 
-template <class T, class S, int F, bool SPLIT = false, bool TW1 = false> KernelEntry make_bluestein(int prec, const char* name) {
+template <class T, class S, int F, bool SPLIT = false, bool TW1 = false, int PF = 0> KernelEntry make_bluestein(int prec, const char* name) {
     KernelEntry e{};
     e.kind = KIND_BLUESTEIN;
     e.prec = prec;
@@ -345,16 +346,16 @@ template <class T, class S, int F, bool SPLIT = false, bool TW1 = false> KernelE
     e.f = F;
     fill_sched<S>(e);
     e.threads = F * S::TPF;
-    e.lds_bytes = bluestein_lds<T, S, F, SPLIT, TW1>();
+    e.lds_bytes = bluestein_lds<T, S, F, SPLIT, TW1, PF>();
     e.name = name;
     e.launch = [](const void* params, long long grid, void* stream) {
         void* args[] = {const_cast<void*>(params)};
-        (void)hipLaunchKernel((const void*)bluestein_kernel<T, S, F, SPLIT, TW1>, dim3((unsigned)grid), dim3(F * S::TPF), args,
-                              bluestein_lds<T, S, F, SPLIT, TW1>(), (hipStream_t)stream);
+        (void)hipLaunchKernel((const void*)bluestein_kernel<T, S, F, SPLIT, TW1, PF>, dim3((unsigned)grid), dim3(F * S::TPF), args,
+                              bluestein_lds<T, S, F, SPLIT, TW1, PF>(), (hipStream_t)stream);
     };
     e.prepare = []() -> int {
-        return (int)hipFuncSetAttribute((const void*)bluestein_kernel<T, S, F, SPLIT, TW1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)bluestein_lds<T, S, F, SPLIT, TW1>());
+        return (int)hipFuncSetAttribute((const void*)bluestein_kernel<T, S, F, SPLIT, TW1, PF>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)bluestein_lds<T, S, F, SPLIT, TW1, PF>());
     };
     return e;
 }
@@ -652,15 +653,15 @@ template <class T> KernelEntry make_pointwise(int prec) {
     e.prepare = []() -> int { return 0; };
     return e;
 }
-template <class T, class S, int F, bool SPLIT = false, bool TW1 = false> constexpr size_t bluestein_lds() {
-    return bluestein_lds_bytes<T, S, F, SPLIT, TW1>();  // exchange buffer of both schedules (+ the staged tables)
+template <class T, class S, int F, bool SPLIT = false, bool TW1 = false, int PF = 0> constexpr size_t bluestein_lds() {
+    return bluestein_lds_bytes<T, S, F, SPLIT, TW1, PF>();  // exchange buffer of both schedules (+ the staged tables)
 }
 template <class T, class S, int F, int MODE> constexpr size_t rader_lds() {
     if (rader_rows_mode(MODE)) return (size_t)RaderRows<S, MODE == 6>::SLOTS * sizeof(cx<T>);  // one row at a time
     if (MODE == 5) return (size_t)F * (rader5_pitch<S>() + 1) * sizeof(cx<T>);       // rows at the larger pitch of the two schedules + F spare slots
     return (size_t)F * (S::pitch() + (MODE >= 1 ? 0 : S::N + 1)) * sizeof(cx<T>);
 }
-template <class T, class S, int F, bool SPLIT = false, bool TW1 = false> KernelEntry make_bluestein(int prec, const char* name) {
+template <class T, class S, int F, bool SPLIT = false, bool TW1 = false, int PF = 0> KernelEntry make_bluestein(int prec, const char* name) {
     KernelEntry e{};
     e.kind = KIND_BLUESTEIN;
     e.prec = prec;
@@ -668,13 +669,13 @@ template <class T, class S, int F, bool SPLIT = false, bool TW1 = false> KernelE
     e.f = F;
     fill_sched<S>(e);
     e.threads = F * S::TPF;
-    e.lds_bytes = bluestein_lds<T, S, F, SPLIT, TW1>();
+    e.lds_bytes = bluestein_lds<T, S, F, SPLIT, TW1, PF>();
     e.name = name;
     e.launch = [](const void* params, long long grid, void*) {
-        std::vector<char> lds(bluestein_lds<T, S, F, SPLIT, TW1>() + 64, (char)0x5a);
+        std::vector<char> lds(bluestein_lds<T, S, F, SPLIT, TW1, PF>() + 64, (char)0x5a);
         for (long long b = 0; b < grid; ++b) {
-            HostExec<T, regs_needed<S, false>()> ex(F * S::TPF);
-            bluestein_body<T, S, F, SPLIT, TW1>(ex, *(const BluesteinParams<T>*)params, b, lds.data());
+            HostExec<T, bluestein_regs<S, PF>()> ex(F * S::TPF);
+            bluestein_body<T, S, F, SPLIT, TW1, PF>(ex, *(const BluesteinParams<T>*)params, b, lds.data());
         }
     };
     e.prepare = []() -> int { return 0; };
@@ -903,14 +904,36 @@ template <class T, class S> constexpr bool bs_tw1() {
 #else
     constexpr int M = S::N;
     if (sizeof(T) == 4)
-        return bluestein_tw1_ok<S>() && (M == 256 || M == 320 || M == 384 || M == 512 || M == 640 || M == 1024 || M == 1280 || M == 1536 || M == 2560 || M == 4096 ||
-                                         M == 5120 || M == 7168 || M == 12288);
+        return bluestein_tw1_ok<S>() && (M == 256 || M == 320 || M == 384 || M == 512 || M == 640 || M == 1024 || M == 1280 || M == 1536 || M == 2560 || M == 3072 ||
+                                         M == 4096 || M == 5120 || M == 7168 || M == 12288);  // (3072: together with bs_pf, round 5)
     return bluestein_tw1_ok<S>() && (M == 896 || M == 1024 || M == 1536 || M == 2560 || M == 4096);
 #endif
 }
-#define MI_BS(T, PREC, F, ...)                                                                                  \
-    reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F, false, bs_tw1<T, SchedL<__VA_ARGS__>>()>(           \
-        PREC, bs_tw1<T, SchedL<__VA_ARGS__>>() ? "bluestein<" #__VA_ARGS__ ">xF" #F "t1" : "bluestein<" #__VA_ARGS__ ">xF" #F))
+// Round 5: where the sub-pass factors that are NOT staged in LDS come from (kernels.h bluestein_body PF) -- a per-inner-length measured choice of
+// the Complex<f32> bodies (profiles/r5/ab_bs_stage_*.jsonl, one prime per inner length, all variants interleaved in one process):
+//   1 = fetched one exchange AHEAD of their sub-pass instead of right behind its barrier: 2048 +1.7 %, 3584 +3.7 %, 3072 (with "t1") +6.2 %;
+//   3 = every table but the last staged in LDS + the last sub-pass's factors fetched ahead: 6144 +10.9 %, 8192 +7.2 %;
+//   0 = as before (4096, 5120, 7168: the staged sub-pass-1 table alone measured best; the prefetch alone loses 8 - 18 % there);
+//   + 4 = the spectrum multiplier fetched in front of the first transform's last sub-pass, + 8 = the output chirp in front of the second one's
+//   (profiles/r5/ab_bs_pre_*.jsonl): 2560 + 12: +3.0 %, 6144 + 4: +2.0 %; within +-1.5 % or slower everywhere else (5120 / 7168: -23 ... -36 %).
+// Kernel names carry the value as "p<PF>".
+// Complex<f64> (profiles/r5/ab_bs_f64_*.jsonl): 1 at 2048 +5.5 %, 2560 (with "t1") +2.3 %, 3072 +4.3 %, 3584 +4.8 %, 5120 +8.0 %, 7168 +1.7 %, 8192 +8.8 %;
+// 4096 and 6144 within +-1 %; staging more tables (2 / 3) loses up to 37 % there (an f64 row fills the LDS: fewer workgroups per CU).
+template <class T, class S> constexpr int bs_pf() {
+    constexpr int M = S::N;
+    if (!bluestein_tw1_ok<S>()) return 0;
+    if (sizeof(T) == 8) return (M == 2048 || M == 2560 || M == 3072 || M == 3584 || M == 5120 || M == 7168 || M == 8192) ? 1 : 0;
+    return (M == 2048 || M == 3072 || M == 3584) ? 1 : M == 8192 ? 3 : M == 6144 ? 7 : M == 2560 ? 12 : 0;
+}
+inline const char* bs_name(const char* base, bool tw1, int pf) {
+    std::string* s = new std::string(base);  // (registered once per kernel at start-up, lives as long as the registry)
+    if (tw1 && !(pf & 2)) *s += "t1";
+    if (pf) *s += "p" + std::to_string(pf);
+    return s->c_str();
+}
+#define MI_BS(T, PREC, F, ...)                                                                                                            \
+    reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F, false, bs_tw1<T, SchedL<__VA_ARGS__>>(), bs_pf<T, SchedL<__VA_ARGS__>>()>( \
+        PREC, bs_name("bluestein<" #__VA_ARGS__ ">xF" #F, bs_tw1<T, SchedL<__VA_ARGS__>>(), bs_pf<T, SchedL<__VA_ARGS__>>())))
 // one-kernel Bluestein through the split exchange (padded lengths above 8192: one workgroup per row)
 #define MI_BSS(T, PREC, F, ...)                                                                                \
     reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F, true, bs_tw1<T, SchedL<__VA_ARGS__>>()>(            \
@@ -919,12 +942,16 @@ template <class T, class S> constexpr bool bs_tw1() {
 #define MI_BSV(V, T, PREC, F, ...)                                                                    \
     reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F "v" #V)); \
     reg.back().variant = V
+#define MI_BSPV(V, PF, T, PREC, F, ...)                                                                                          \
+    reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F, false, ((PF) & 16) != 0, ((PF) & 15)>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F "pf" #PF "v" #V)); \
+    reg.back().variant = V
 #define MI_BSSV(V, T, PREC, F, ...)                                                                          \
     reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F, true>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F "sv" #V)); \
     reg.back().variant = V
 #else
 #define MI_BSV(V, T, PREC, F, ...) (void)0
 #define MI_BSSV(V, T, PREC, F, ...) (void)0
+#define MI_BSPV(V, PF, T, PREC, F, ...) (void)0
 #endif
 #define MI_RADER(T, PREC, F, MODE, ...) reg.push_back(make_rader<T, Sched<__VA_ARGS__>, F, MODE>(PREC, "rader<" #__VA_ARGS__ ">xF" #F "m" #MODE))
 #if defined(MI355_TUNING)

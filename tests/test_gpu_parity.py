@@ -1117,6 +1117,16 @@ def test_multi_device_plan_on_one_gpu(planners, oracle, dtype):
             multi.synchronize()
             assert rel_l2(out.cpu().numpy(), a) < 1e-6, (n, d, "device shards")
     multi = mp.plan_fft(1024, 0)
+    # NUMA placement (round 5): the workers are bound to their GPU's node exactly when sysfs names one for the device (real hardware: the
+    # list is the node's cores; a one-socket box or a container without the node files: unbound); the calling thread is never re-bound
+    cpus = rustfft_amd.device_cpulist(0)
+    node = set()
+    for part in filter(None, cpus.split(",")):
+        lo, _, hi = part.partition("-")
+        node.update(range(int(lo), int(hi or lo) + 1))
+    expect = bool(node & os.sched_getaffinity(0))  # (a cpuset that excludes the whole node leaves nothing to bind to)
+    assert [multi.shard_pinned(g) for g in range(2)] == [expect] * 2, (cpus, [multi.shard_pinned(g) for g in range(2)])
+    print("device 0 sits on the NUMA node with CPUs", repr(cpus))
     with pytest.raises(FftPanic, match="multiple of FFT length"):
         multi.process(random_signal(1024 * 3 + 1, dtype))
     with pytest.raises(FftPanic, match="same length"):
