@@ -918,8 +918,20 @@ template <class T, class S2> struct RaderRegSrc {
         });
     }
 };
+// MI355_RADER_PF (a probe build, tools/r5/build_rader_pf.sh): the sub-pass factors of the non-rows-loop bodies (MODE 1 / 5) fetched one exchange
+// ahead of their sub-pass (engine.h TWSTAGE), as the Bluestein bodies do
+#if defined(MI355_RADER_PF)
+constexpr bool kRaderPF = true;
+#else
+constexpr bool kRaderPF = false;
+#endif
+template <class S> constexpr int rader_regs() {
+    using S2 = typename reversed_sched<S>::type;
+    return S::emax() + (kRaderPF ? (twreg_count<S>() > twreg_count<S2>() ? twreg_count<S>() : twreg_count<S2>()) : 0);
+}
 template <class T, class S, int F, int MODE, class X>
 MI_HD void rader_body(X& ex, const RaderParams<T>& p, long long block, void* lds) {
+    constexpr int RTW = kRaderPF ? S::emax() : -1;
     constexpr int M = S::N, P = S::N + 1, PITCH = (MODE == 5) ? rader5_pitch<S>() : S::pitch(), NT = F * S::TPF;
     const long long fft0 = block * F;
     const cx<T>* in = p.in;
@@ -986,10 +998,10 @@ MI_HD void rader_body(X& ex, const RaderParams<T>& p, long long block, void* lds
             using S2 = typename reversed_sched<S>::type;
             static_assert(S2::R[0] == S::R[S::NP - 1] && S2::nb(0) == S::nb(S::NP - 1) && S2::bpt(0) == S::bpt(S::NP - 1) && S2::TPF == S::TPF,
                           "register hand-over");
-            wg_fft<T, S, F, MAP_EF, MAP_EF, false, true>(ex, lds, p.tw, elem_src(src1), KeepInRegs{});
+            wg_fft<T, S, F, MAP_EF, MAP_EF, false, true, 1, 0, RTW, kRaderPF>(ex, lds, p.tw, elem_src(src1), KeepInRegs{});
             // (the barrier after the last gather of the first transform orders it before the second one's scatters; the natural-
             // order outputs are written after the second transform's last gather + barrier, when no exchange data is live)
-            wg_fft<T, S2, F, MAP_EF, MAP_EF, false, false>(ex, lds, p.tw2, RaderRegSrc<T, S2>{dtab, work + F * PITCH}, dst2);
+            wg_fft<T, S2, F, MAP_EF, MAP_EF, false, false, 1, 0, RTW, kRaderPF>(ex, lds, p.tw2, RaderRegSrc<T, S2>{dtab, work + F * PITCH}, dst2);
         } else {
             auto dst1 = [=](int f, int j, cx<T> v) {
                 cx<T> t = cconj(v * dtab[j]);
@@ -1000,9 +1012,9 @@ MI_HD void rader_body(X& ex, const RaderParams<T>& p, long long block, void* lds
                 }
                 work[f * PITCH + j] = t;
             };
-            wg_fft<T, S, F, MAP_EF, MAP_EF, false, true>(ex, lds, p.tw, elem_src(src1), dst1);
+            wg_fft<T, S, F, MAP_EF, MAP_EF, false, true, 1, 0, RTW, kRaderPF>(ex, lds, p.tw, elem_src(src1), dst1);
             ex.barrier();
-            wg_fft<T, S, F, MAP_EF, MAP_EF, false, true>(ex, lds, p.tw, elem_src(src1), dst2);
+            wg_fft<T, S, F, MAP_EF, MAP_EF, false, true, 1, 0, RTW, kRaderPF>(ex, lds, p.tw, elem_src(src1), dst2);
         }
         ex.barrier();
         ex.for_threads([&](int tid, cx<T>*) {

@@ -307,7 +307,7 @@ __global__ __launch_bounds__((rader_rows_mode(MODE) ? 1 : F) * S::TPF, (MODE == 
         DevExecLoop<T, RaderRows<S, MODE == 6>::NREG> ex;
         rader_rows_body<T, S, F, MODE == 2 || MODE == 4 || MODE == 6, MODE == 6>(ex, p, (long long)blockIdx.x, smem);
     } else {
-        DevExec<T, regs_needed<S, false>()> ex;
+        DevExec<T, rader_regs<S>()> ex;
         rader_body<T, S, F, MODE>(ex, p, (long long)blockIdx.x, smem);
     }
 }
@@ -700,7 +700,7 @@ template <class T, class S, int F, int MODE> KernelEntry make_rader(int prec, co
                 HostExec<T, RaderRows<S, MODE == 6>::NREG> ex(S::TPF);
                 rader_rows_body<T, S, F, MODE == 2 || MODE == 4 || MODE == 6, MODE == 6>(ex, *(const RaderParams<T>*)params, b, lds.data());
             } else {
-                HostExec<T, regs_needed<S, false>()> ex(F * S::TPF);
+                HostExec<T, rader_regs<S>()> ex(F * S::TPF);
                 rader_body<T, S, F, MODE>(ex, *(const RaderParams<T>*)params, b, lds.data());
             }
         }
