@@ -108,3 +108,25 @@ def test_general_tile_units_match_the_noslp_choice():
     want = [x for x in gk.g.smooth(640, [2, 3, 5, 7, 11, 13]) if x >= 25]
     assert sorted(seen) == want
     assert {h for h, u in seen.items() if u.startswith("ns")} == choice & set(want) == gk.NOSLP_F32 & set(want)
+
+
+def test_non_temporal_choice_is_what_the_generated_units_carry():
+    """tools/smooth_nt_choice.json (round 5: per-length measured choice of non-temporal row loads / loads + stores in the compiled whole-row
+    schedules): exactly the listed lengths carry the ABL bits 16 / 48 and the name suffix "n" / "nn" in the generated units."""
+    import json
+
+    choice = json.load(open(os.path.join(ROOT, "tools", "smooth_nt_choice.json")))
+    csrc = os.path.join(ROOT, "rustfft_amd", "csrc")
+    for tag, ty in (("f32", "float"), ("f64", "double")):
+        loads, both = set(), set()
+        for fn in sorted(os.listdir(csrc)):
+            if not re.fullmatch(rf"kernels_smooth\d?_{tag}_\w+\.hip", fn):
+                continue
+            for m in re.finditer(rf'MI_K1X\({ty}, \d+, \d+, (?:true|false), (\d+), "(\w*)", (\d+),', open(os.path.join(csrc, fn)).read()):
+                abl, suf, n = int(m.group(1)), m.group(2), int(m.group(3))
+                assert (abl & 48) in (0, 16, 48) and suf.endswith("nn") == ((abl & 48) == 48) and (suf.endswith("n") and not suf.endswith("nn")) == ((abl & 48) == 16), (fn, n, abl, suf)
+                if (abl & 48) == 16:
+                    loads.add(n)
+                elif (abl & 48) == 48:
+                    both.add(n)
+        assert loads == set(choice[tag + "_loads"]) and both == set(choice[tag + "_both"]), (tag, sorted(loads ^ set(choice[tag + "_loads"]))[:10], sorted(both ^ set(choice[tag + "_both"]))[:10])

@@ -22,9 +22,13 @@ NP2=3,7,17,77,100,127,251,289,360,719,899,1000,1001,1009,1019,1200,1201,1517,200
 python tools/sweep.py --dtype f32 --sizes $NP2 --check > $OUT/sweep_np2_f32.jsonl 2>/dev/null
 python tools/sweep.py --dtype f64 --sizes $NP2 --check > $OUT/sweep_np2_f64.jsonl 2>/dev/null
 python tools/prime_sweep.py > $OUT/primes_le_4096_f32.json 2>/dev/null
+python tools/prime_sweep.py --dtype f64 > $OUT/primes_le_4096_f64.json 2>/dev/null
 python tools/ab_lengths.py --a libmi355fft.so --b libmi355fft.so --all --sizes-file tools/r5/smooth13_4096_20000.txt --dtype f32 --gib 1 > $OUT/abs_smooth13_4096_20000_f32.jsonl 2>/dev/null
 python bench.py --gpus 2 --one-device --dist-backend gloo --steps 2 --warmup 1 --batch 64 --no-pmc --no-cpu-baseline > $OUT/bench_2rank_one_gpu_smoke.json 2>/dev/null
 python bench.py --via-cabi --gpus 2 --one-device --batch 512 > $OUT/bench_via_cabi_2shards_one_gpu.json 2>/dev/null
 python tools/fuzz_gpu.py > $OUT/fuzz_gpu.log 2>&1
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke_final.log 2>&1
+python -m pytest tests -m gpu -q -s > $OUT/pytest_gpu.log 2>&1
+python tools/pmc_sq.py --config c4 > $OUT/sq_counters_c4.jsonl 2>/dev/null
+python tools/pmc_sq.py --sweep --dtype f32 --sizes 3067,4091 > $OUT/sq_counters_bluestein_6144_8192.jsonl 2>/dev/null
 ls -la $OUT
