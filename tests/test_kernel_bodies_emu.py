@@ -731,7 +731,9 @@ def test_thread_order_independence(emu_planner, oracle):
     unless the order changes: MI355_EMU_ORDER=reverse runs every phase from the last thread to the first.  Results must not
     depend on the order (round 2: the Rader bodies kept X[0] in a slot that the output with g^-(j+1) = p - 1 also wrote
     whenever the schedule's LDS layout is unpadded -- invisible in thread order, wrong in reverse order, a coin toss on the GPU)."""
-    lengths = [541, 911, 1009, 127, 257, 1201, 2311, 1297, 2003, 2081, 727, 2801, 613, 683, 2143, 2053, 719, 1019, 1200, 1281, 2311 + 2, 4096, 1 << 13, 1 << 16, 44100, 289, 992]
+    lengths = [541, 911, 1009, 127, 257, 1201, 2311, 1297, 2003, 2081, 727, 2801, 613, 683, 2143, 2053, 719, 1019, 1200, 1281, 2311 + 2, 4096, 1 << 13, 1 << 16, 44100, 289, 992,
+               # round 5: the Bluestein bodies with staged / prefetched sub-pass factors (2560, 3072, 3584, 6144, 8192) and whole-row kernels with the factors 11 / 13
+               1279, 1523, 1789, 3067, 4091, 5005, 9009]
     os.environ["MI355_EMU_ORDER"] = "reverse"
     try:
         for dtype in (np.complex64, np.complex128):
