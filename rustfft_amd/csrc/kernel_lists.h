@@ -42,7 +42,9 @@
     MI_BS(T, PREC, 1, 768, 64, 12, 8, 8);  \
     MI_BS(T, PREC, 1, 1536, 256, 6, 16, 16);  \
     MI_BS(T, PREC, 1, 3072, 256, 12, 16, 16);  \
-    MI_BS(T, PREC, 1, 6144, 512, 6, 8, 8, 16)
+    MI_BS(T, PREC, 1, 6144, 768, 8, 8, 8, 12)
+// (6144, round 5: 768 threads x 8 values -- 12 in the last sub-pass -- instead of 512 x 12 on 6 x 8 x 8 x 16: +5 % with the tables staged and the last
+// sub-pass's factors fetched ahead, profiles/r5/ab_bs_threads_3067.jsonl; the old schedule: tuning 6)
 #define MI_BS_LIST3_F64(T, PREC)                  \
     MI_BS(T, PREC, 256, 12, 1, 12);  \
     MI_BS(T, PREC, 128, 24, 2, 12, 2);  \

@@ -49,5 +49,20 @@ void register_bs57_f32(std::vector<KernelEntry>& reg) {
     MI_BSPV(70, 20, float, 32, 1, 7168, 512, 16, 16, 28);
     MI_BSPV(71, 28, float, 32, 1, 7168, 512, 16, 16, 28);
     MI_BSPV(72, 24, float, 32, 1, 7168, 512, 16, 16, 28);
+    // round 5, tuning 80: the shipped body of each inner length with TWO rows per physical thread (launch.h DevExecRows2)
+    MI_BSR2V(80, 28, float, 32, 2560, 256, 10, 16, 16);
+    MI_BSR2V(80, 1, float, 32, 3584, 256, 14, 16, 16);
+    MI_BSR2V(80, 16, float, 32, 5120, 512, 10, 8, 8, 8);
+    MI_BSR2V(80, 16, float, 32, 7168, 512, 16, 16, 28);
+    MI_BSR2V(80, 16, float, 32, 1280, 128, 10, 8, 16);
+    // round 5, tuning 81 / 82: more threads per row, 8 values per thread
+    MI_BSPV(81, 16, float, 32, 1, 5120, 640, 8, 8, 8, 10);
+    MI_BSPV(82, 1, float, 32, 1, 5120, 640, 8, 8, 8, 10);
+    MI_BSPV(81, 16, float, 32, 1, 7168, 896, 8, 8, 8, 14);
+    MI_BSPV(82, 1, float, 32, 1, 7168, 896, 8, 8, 8, 14);
+    MI_BSPV(81, 16, float, 32, 1, 3584, 448, 8, 8, 8, 7);
+    MI_BSPV(82, 1, float, 32, 1, 3584, 448, 8, 8, 8, 7);
+    MI_BSPV(81, 16, float, 32, 1, 2560, 320, 8, 8, 8, 5);
+    MI_BSPV(82, 1, float, 32, 1, 2560, 320, 8, 8, 8, 5);
 }
 }  // namespace mi355

@@ -44,5 +44,21 @@ void register_bs_f32(std::vector<KernelEntry>& reg) {
     MI_BSPV(70, 7, float, 32, 1, 8192, 512, 8, 8, 8, 16);
     MI_BSPV(71, 15, float, 32, 1, 8192, 512, 8, 8, 8, 16);
     MI_BSPV(72, 11, float, 32, 1, 8192, 512, 8, 8, 8, 16);
+    // round 5, tuning 80: the shipped body of each inner length with TWO rows per physical thread (launch.h DevExecRows2)
+    MI_BSR2V(80, 17, float, 32, 3072, 256, 12, 16, 16);
+    MI_BSR2V(80, 16, float, 32, 4096, 512, 8, 8, 8, 8);
+    MI_BSR2V(80, 7, float, 32, 6144, 512, 6, 8, 8, 16);
+    MI_BSR2V(80, 3, float, 32, 8192, 512, 8, 8, 8, 16);
+    MI_BSR2V(80, 16, float, 32, 1024, 128, 8, 8, 16);
+    MI_BSR2V(80, 16, float, 32, 1536, 256, 6, 16, 16);
+    // round 5, tuning 81 / 82: MORE threads per row, 8 values per thread (the two-rows-per-thread form, tuning 80, measured -17 ... -45 %: these bodies want more waves, not fewer)
+    MI_BSPV(81, 3, float, 32, 1, 8192, 1024, 8, 8, 8, 16);
+    MI_BSPV(82, 1, float, 32, 1, 8192, 1024, 8, 8, 8, 16);
+    MI_BSPV(6, 7, float, 32, 1, 6144, 512, 6, 8, 8, 16);  // the schedule shipped until round 5 (with its staging / prefetch choice)
+    MI_BSPV(82, 1, float, 32, 1, 6144, 768, 8, 8, 8, 12);
+    MI_BSPV(81, 17, float, 32, 1, 3072, 384, 8, 8, 8, 6);
+    MI_BSPV(82, 1, float, 32, 1, 3072, 384, 8, 8, 8, 6);
+    MI_BSPV(83, 1, float, 32, 1, 8192, 1024, 8, 8, 8, 8, 2);  // five sub-passes, 8 values per thread throughout
+    MI_BSPV(83, 1, float, 32, 1, 6144, 768, 8, 8, 8, 6, 2);
 }
 }  // namespace mi355

@@ -87,5 +87,7 @@ void register_np2_f32(std::vector<KernelEntry>& reg) {
     MI_BSPV(70, 5, float, 32, 1, 2048, 128, 8, 16, 16);
     MI_BSPV(71, 13, float, 32, 1, 2048, 128, 8, 16, 16);
     MI_BSPV(72, 9, float, 32, 1, 2048, 128, 8, 16, 16);
+    // round 5, tuning 80: the shipped body of each inner length with TWO rows per physical thread (launch.h DevExecRows2)
+    MI_BSR2V(80, 1, float, 32, 2048, 128, 8, 16, 16);
 }
 }  // namespace mi355

@@ -298,6 +298,46 @@ __global__ __launch_bounds__(F* S::TPF) void bluestein_kernel(BluesteinParams<T>
     DevExec<T, bluestein_regs<S, PF>()> ex;
     bluestein_body<T, S, F, SPLIT, TW1, PF>(ex, p, (long long)blockIdx.x, smem);
 }
+// Two ROWS per physical thread (round 5, tuning): the engine sees a workgroup of 2 x blockDim threads transforming F = 2 rows (MAP_EF: virtual
+// thread t + blockDim is slot t of row 1); physical thread t runs both, one after the other in every phase, each on its own half of the register
+// array.  A barrier then serves two rows -- half the barriers per row, two independent dependency chains per thread -- at half the waves per row.
+template <class T, int NREG> struct DevExecRows2 {
+    cx<T> v[2 * NREG];
+    template <class Fn> __device__ __forceinline__ void for_threads(Fn&& fn) {
+        fn((int)threadIdx.x, v);
+        fn((int)threadIdx.x + (int)blockDim.x, v + NREG);
+    }
+    __device__ __forceinline__ void barrier() { __syncthreads(); }
+    __device__ __forceinline__ void relaunder() {}
+    __device__ __forceinline__ void pair_swap() {}
+};
+template <class T, class S, bool SPLIT, bool TW1, int PF>
+__global__ __launch_bounds__(S::TPF) void bluestein_rows2_kernel(BluesteinParams<T> p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DevExecRows2<T, bluestein_regs<S, PF>()> ex;
+    bluestein_body<T, S, 2, SPLIT, TW1, PF>(ex, p, (long long)blockIdx.x, smem);
+}
+template <class T, class S, bool SPLIT, bool TW1, int PF> KernelEntry make_bluestein_rows2(int prec, const char* name) {
+    KernelEntry e{};
+    e.kind = KIND_BLUESTEIN;
+    e.prec = prec;
+    e.n = S::N;
+    e.f = 2;
+    fill_sched<S>(e);
+    e.threads = S::TPF;
+    e.lds_bytes = bluestein_lds_bytes<T, S, 2, SPLIT, TW1, PF>();
+    e.name = name;
+    e.launch = [](const void* params, long long grid, void* stream) {
+        void* args[] = {const_cast<void*>(params)};
+        (void)hipLaunchKernel((const void*)bluestein_rows2_kernel<T, S, SPLIT, TW1, PF>, dim3((unsigned)grid), dim3(S::TPF), args,
+                              bluestein_lds_bytes<T, S, 2, SPLIT, TW1, PF>(), (hipStream_t)stream);
+    };
+    e.prepare = []() -> int {
+        return (int)hipFuncSetAttribute((const void*)bluestein_rows2_kernel<T, S, SPLIT, TW1, PF>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)bluestein_lds_bytes<T, S, 2, SPLIT, TW1, PF>());
+    };
+    return e;
+}
 template <class T, class S, int F, int MODE>
 // MODE 2: rows loop with next-row prefetch (>= 3 waves per SIMD in f32); MODE 3: without the prefetch; MODE 4: as MODE 2 for the
 // larger primes whose per-thread tables need up to 256 VGPRs (two waves per SIMD)
@@ -681,6 +721,11 @@ template <class T, class S, int F, bool SPLIT = false, bool TW1 = false, int PF 
     e.prepare = []() -> int { return 0; };
     return e;
 }
+template <class T, class S, bool SPLIT, bool TW1, int PF> KernelEntry make_bluestein_rows2(int prec, const char* name) {
+    KernelEntry e = make_bluestein<T, S, 2, SPLIT, TW1, PF>(prec, name);  // the emulator runs every (virtual) thread anyway
+    e.threads = S::TPF;
+    return e;
+}
 template <class T, class S, int F, int MODE> KernelEntry make_rader(int prec, const char* name) {
     KernelEntry e{};
     e.split = (MODE >= 1);  // Rader: perm_in is the inverse map (kernels.h rader_body MODE 1, rader_rows_body)
@@ -915,7 +960,7 @@ template <class T, class S> constexpr bool bs_tw1() {
 //   3 = every table but the last staged in LDS + the last sub-pass's factors fetched ahead: 6144 +10.9 %, 8192 +7.2 %;
 //   0 = as before (4096, 5120, 7168: the staged sub-pass-1 table alone measured best; the prefetch alone loses 8 - 18 % there);
 //   + 4 = the spectrum multiplier fetched in front of the first transform's last sub-pass, + 8 = the output chirp in front of the second one's
-//   (profiles/r5/ab_bs_pre_*.jsonl): 2560 + 12: +3.0 %, 6144 + 4: +2.0 %; within +-1.5 % or slower everywhere else (5120 / 7168: -23 ... -36 %).
+//   (profiles/r5/ab_bs_pre_*.jsonl): 2560 + 12: +3.0 %; within +-2 % or slower everywhere else (5120 / 7168: -23 ... -36 %).
 // Kernel names carry the value as "p<PF>".
 // Complex<f64> (profiles/r5/ab_bs_f64_*.jsonl): 1 at 2048 +5.5 %, 2560 (with "t1") +2.3 %, 3072 +4.3 %, 3584 +4.8 %, 5120 +8.0 %, 7168 +1.7 %, 8192 +8.8 %;
 // 4096 and 6144 within +-1 %; staging more tables (2 / 3) loses up to 37 % there (an f64 row fills the LDS: fewer workgroups per CU).
@@ -923,7 +968,7 @@ template <class T, class S> constexpr int bs_pf() {
     constexpr int M = S::N;
     if (!bluestein_tw1_ok<S>()) return 0;
     if (sizeof(T) == 8) return (M == 2048 || M == 2560 || M == 3072 || M == 3584 || M == 5120 || M == 7168 || M == 8192) ? 1 : 0;
-    return (M == 2048 || M == 3072 || M == 3584) ? 1 : M == 8192 ? 3 : M == 6144 ? 7 : M == 2560 ? 12 : 0;
+    return (M == 2048 || M == 3072 || M == 3584) ? 1 : (M == 8192 || M == 6144) ? 3 : M == 2560 ? 12 : 0;
 }
 inline const char* bs_name(const char* base, bool tw1, int pf) {
     std::string* s = new std::string(base);  // (registered once per kernel at start-up, lives as long as the registry)
@@ -945,6 +990,9 @@ inline const char* bs_name(const char* base, bool tw1, int pf) {
 #define MI_BSPV(V, PF, T, PREC, F, ...)                                                                                          \
     reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F, false, ((PF) & 16) != 0, ((PF) & 15)>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F "pf" #PF "v" #V)); \
     reg.back().variant = V
+#define MI_BSR2V(V, PF, T, PREC, ...)                                                                                            \
+    reg.push_back(make_bluestein_rows2<T, SchedL<__VA_ARGS__>, false, ((PF) & 16) != 0, ((PF) & 15)>(PREC, "bluestein<" #__VA_ARGS__ ">xR2pf" #PF "v" #V)); \
+    reg.back().variant = V
 #define MI_BSSV(V, T, PREC, F, ...)                                                                          \
     reg.push_back(make_bluestein<T, SchedL<__VA_ARGS__>, F, true>(PREC, "bluestein<" #__VA_ARGS__ ">xF" #F "sv" #V)); \
     reg.back().variant = V
@@ -952,6 +1000,7 @@ inline const char* bs_name(const char* base, bool tw1, int pf) {
 #define MI_BSV(V, T, PREC, F, ...) (void)0
 #define MI_BSSV(V, T, PREC, F, ...) (void)0
 #define MI_BSPV(V, PF, T, PREC, F, ...) (void)0
+#define MI_BSR2V(V, PF, T, PREC, ...) (void)0
 #endif
 #define MI_RADER(T, PREC, F, MODE, ...) reg.push_back(make_rader<T, Sched<__VA_ARGS__>, F, MODE>(PREC, "rader<" #__VA_ARGS__ ">xF" #F "m" #MODE))
 #if defined(MI355_TUNING)
