@@ -54,8 +54,12 @@ MI_HD void k1_body(X& ex, const K1Params<T>& p, long long block, void* lds) {
                 out[(unsigned)(f * S::N + i)] = x;
         }
     };
-    wg_fft<T, S, F, MAP_EF, MAP_EF, SPLIT, false, 1, (ABL & 15), -1, false, k1_twl<ABL, S::NP>()>(ex, lds, p.tw, elem_src(src), dst);
+    // ABL bit 8 (256; tuning so far, round 5): the factors of the sub-passes whose tables are not staged in LDS are fetched one exchange ahead of
+    // their use (engine.h TWSTAGE), as the Bluestein bodies do
+    constexpr bool PFK = (ABL & 256) != 0;
+    wg_fft<T, S, F, MAP_EF, MAP_EF, SPLIT, false, 1, (ABL & 15), (PFK ? S::emax() : -1), PFK, k1_twl<ABL, S::NP>()>(ex, lds, p.tw, elem_src(src), dst);
 }
+template <class S, bool SPLIT, int ABL> constexpr int k1_regs() { return regs_needed<S, SPLIT>() + ((ABL & 256) ? twreg_count<S>() : 0); }
 template <class T, class S, int F, bool SPLIT, int ABL> constexpr size_t k1_lds_bytes() {
     return lds_bytes_twl<T, S, F, SPLIT, 1, k1_twl<ABL, S::NP>()>();
 }

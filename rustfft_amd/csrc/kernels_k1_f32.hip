@@ -93,6 +93,13 @@ void register_k1_f32(std::vector<KernelEntry>& reg) {
     MI_K1ABL(50, 1072, float, 32, 1, true, 32768, 1024, 32, 32, 32);
     MI_K1ABL(51, 1040, float, 32, 1, true, 32768, 1024, 32, 32, 32);
     MI_K1ABL(52, 1056, float, 32, 1, true, 32768, 1024, 32, 32, 32);
+    // round 5, tuning 53: the shipped kernels + sub-pass factors fetched one exchange ahead (ABL bit 256)
+    MI_K1ABL(53, 1280, float, 32, 4, false, 1024, 64, 16, 16, 4);
+    MI_K1ABL(53, 1280, float, 32, 2, false, 2048, 128, 16, 16, 8);
+    MI_K1ABL(53, 1280, float, 32, 1, false, 4096, 256, 16, 16, 16);
+    MI_K1ABL(53, 1296, float, 32, 1, true, 8192, 256, 8, 32, 32);
+    MI_K1ABL(53, 1296, float, 32, 1, true, 16384, 512, 16, 32, 32);
+    MI_K1ABL(53, 1280, float, 32, 1, true, 32768, 1024, 32, 32, 32);
     // sub-pass twiddle tables staged in LDS: all (30) / sub-pass 1 only (31) / last sub-pass only (32)
     MI_K1ABL(30, 128, float, 32, 4, false, 1024, 64, 16, 16, 4);
     MI_K1ABL(31, 1024, float, 32, 4, false, 1024, 64, 16, 16, 4);

@@ -67,7 +67,7 @@ template <class T, int NREG> struct DevExecLoop {
 template <class T, class S, int F, bool SPLIT, int ABL = 0>
 __global__ __launch_bounds__(F* S::TPF) void k1_kernel(K1Params<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    DevExec<T, regs_needed<S, SPLIT>()> ex;
+    DevExec<T, k1_regs<S, SPLIT, ABL>()> ex;
     k1_body<T, S, F, SPLIT, ABL>(ex, p, (long long)blockIdx.x, smem);
 }
 // two workgroups per CU is what keeps HBM busy while the other workgroup computes: ask the register
@@ -607,7 +607,7 @@ template <class T, class S, int F, bool SPLIT, int ABL = 0> KernelEntry make_k1(
     e.launch = [](const void* params, long long grid, void*) {
         std::vector<char> lds(k1_lds_bytes<T, S, F, SPLIT, ABL>() + 64, (char)0x5a);  // poisoned LDS
         for (long long b = 0; b < grid; ++b) {
-            HostExec<T, regs_needed<S, SPLIT>()> ex(F * S::TPF);
+            HostExec<T, k1_regs<S, SPLIT, ABL>()> ex(F * S::TPF);
             k1_body<T, S, F, SPLIT, ABL>(ex, *(const K1Params<T>*)params, b, lds.data());
         }
     };
