@@ -889,7 +889,9 @@ template <class T> MI_HD void pointwise_elem(const PointwiseParams<T>& p, long l
 //   p - 1 elements and one barrier fewer per row.  Rows sit at the larger pitch of the two schedules; x[0] / X[0] of row f live
 //   in slot F PITCH + f, behind every row, because the two schedules' exchange spans differ.
 // Body forms 2 / 3 / 4 are the rows loop (rader_rows_body); 6 is the rows loop with the same register hand-over.
-constexpr bool rader_rows_mode(int mode) { return (mode >= 2 && mode <= 4) || mode == 6; }
+// (MODE 9, round 5: MODE 3 with non-temporal row loads -- config 4's prime: +2.1 / +2.2 % at its full batch, profiles/r5/ab_c4_nt.jsonl; the same
+// hint in every other rows loop measured nothing, ab_rader_nt_*.jsonl)
+constexpr bool rader_rows_mode(int mode) { return (mode >= 2 && mode <= 4) || mode == 6 || mode == 9; }
 template <class S> constexpr int rader5_pitch() {
     using S2 = typename reversed_sched<S>::type;
     return S::pitch() > S2::pitch() ? S::pitch() : S2::pitch();
@@ -1137,7 +1139,7 @@ template <class T, class S2, int D0> struct RaderRowsRegSrc {
         });
     }
 };
-template <class T, class S, int ROWS, bool PREFETCH, bool HO = false, class X>
+template <class T, class S, int ROWS, bool PREFETCH, bool HO = false, bool NTL = false, class X>
 MI_HD void rader_rows_body(X& ex, const RaderParams<T>& p, long long block, void* lds) {
     using L = RaderRows<S, HO>;
     using S2 = typename L::S2;
@@ -1208,11 +1210,15 @@ MI_HD void rader_rows_body(X& ex, const RaderParams<T>& p, long long block, void
                     x = v[L::XN0 + i];
                 } else {
                     const int t = tid + i * NT;
-#if defined(MI355_NT_PROBE)  // probe build (make tuning-min MINEXTRA=-DMI355_NT_PROBE): the rows loop reads its rows with non-temporal loads
-                    x = ((i + 1) * NT <= P || t < P) ? ld_nt(in + (row * P + t)) : cx<T>{0, 0};
+#if defined(MI355_NT_PROBE)  // probe build (make tuning-min MINEXTRA=-DMI355_NT_PROBE): EVERY rows loop reads its rows with non-temporal loads
+                    constexpr bool kNtRows = true;
 #else
-                    x = ((i + 1) * NT <= P || t < P) ? in[row * P + t] : cx<T>{0, 0};
+                    constexpr bool kNtRows = NTL;
 #endif
+                    if constexpr (kNtRows)
+                        x = ((i + 1) * NT <= P || t < P) ? ld_nt(in + (row * P + t)) : cx<T>{0, 0};
+                    else
+                        x = ((i + 1) * NT <= P || t < P) ? in[row * P + t] : cx<T>{0, 0};
                 }
                 x.im *= sgn;
                 work[reg_to_idx<T>(v[L::PI0 + i])] = x;

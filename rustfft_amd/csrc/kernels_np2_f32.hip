@@ -26,6 +26,7 @@ void register_np2_f32(std::vector<KernelEntry>& reg) {
     // (the PRODUCTION body of 1009 is generated now -- kernels_rader_f32_ns*.hip, tools/gen_rader_kernels.py FORCE: the rows loop without
     // the next-row prefetch at four waves per SIMD, compiled without the SLP vectoriser; the round-1 .. 3 body is tuning variant 72)
     MI_RADERV(72, float, 32, 8, 2, 1008, 126, 14, 9, 8);
+    MI_RADERV(73, float, 32, 8, 9, 1008, 126, 14, 9, 8);  // mode 9 = mode 3 + non-temporal row loads (round 5: +1.3 % at config 4's batch, -2 % at 1 GiB; not shipped)
 #if defined(MI355_MINIMAL) && !defined(MI355_MINIMAL_RADER)
     MI_RADER(float, 32, 8, 3, 1008, 126, 14, 9, 8);  // `make tuning-min` carries no generated Rader unit: a default body, so that MI355FFT_VARIANT finds the prime
 #endif

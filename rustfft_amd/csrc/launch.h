@@ -339,13 +339,13 @@ template <class T, class S, bool SPLIT, bool TW1, int PF> KernelEntry make_blues
     return e;
 }
 template <class T, class S, int F, int MODE>
-// MODE 2: rows loop with next-row prefetch (>= 3 waves per SIMD in f32); MODE 3: without the prefetch; MODE 4: as MODE 2 for the
+// MODE 2: rows loop with next-row prefetch (>= 3 waves per SIMD in f32); MODE 3: without the prefetch (MODE 9: + non-temporal row loads); MODE 4: as MODE 2 for the
 // larger primes whose per-thread tables need up to 256 VGPRs (two waves per SIMD)
-__global__ __launch_bounds__((rader_rows_mode(MODE) ? 1 : F) * S::TPF, (MODE == 2 ? (sizeof(T) == 4 ? 3 : 2) : MODE == 3 ? (sizeof(T) == 4 ? 4 : 2) : (MODE == 4 || MODE == 6) ? 2 : 1)) void rader_kernel(RaderParams<T> p) {
+__global__ __launch_bounds__((rader_rows_mode(MODE) ? 1 : F) * S::TPF, (MODE == 2 ? (sizeof(T) == 4 ? 3 : 2) : (MODE == 3 || MODE == 9) ? (sizeof(T) == 4 ? 4 : 2) : (MODE == 4 || MODE == 6) ? 2 : 1)) void rader_kernel(RaderParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if constexpr (rader_rows_mode(MODE)) {  // F = rows pushed through one workgroup one after another
         DevExecLoop<T, RaderRows<S, MODE == 6>::NREG> ex;
-        rader_rows_body<T, S, F, MODE == 2 || MODE == 4 || MODE == 6, MODE == 6>(ex, p, (long long)blockIdx.x, smem);
+        rader_rows_body<T, S, F, MODE == 2 || MODE == 4 || MODE == 6, MODE == 6, MODE == 9>(ex, p, (long long)blockIdx.x, smem);
     } else {
         DevExec<T, rader_regs<S>()> ex;
         rader_body<T, S, F, MODE>(ex, p, (long long)blockIdx.x, smem);
@@ -743,7 +743,7 @@ template <class T, class S, int F, int MODE> KernelEntry make_rader(int prec, co
         for (long long b = 0; b < grid; ++b) {
             if constexpr (rader_rows_mode(MODE)) {
                 HostExec<T, RaderRows<S, MODE == 6>::NREG> ex(S::TPF);
-                rader_rows_body<T, S, F, MODE == 2 || MODE == 4 || MODE == 6, MODE == 6>(ex, *(const RaderParams<T>*)params, b, lds.data());
+                rader_rows_body<T, S, F, MODE == 2 || MODE == 4 || MODE == 6, MODE == 6, MODE == 9>(ex, *(const RaderParams<T>*)params, b, lds.data());
             } else {
                 HostExec<T, rader_regs<S>()> ex(F * S::TPF);
                 rader_body<T, S, F, MODE>(ex, *(const RaderParams<T>*)params, b, lds.data());

@@ -33,7 +33,7 @@ SKIP = {(64, 1009)}  # (prec, p): hand-tuned instantiation in kernels_np2_f64.hi
 # config 4's prime, Complex<f32>: the rows loop WITHOUT the next-row prefetch (MODE 3, 124 VGPRs: four waves per SIMD) compiled without the
 # SLP vectoriser: 4.85 -> 4.35 ms for 2^19 rows (+11 %; with the vectoriser MODE 3 spills at the 128-VGPR cap: 5.88;
 # profiles/r4/ab_c4_noslp_variants.jsonl, ab_c4_mode3_variants.jsonl: 16 or 32 rows per workgroup the same, other schedules spill)
-FORCE = {(32, 1009): (8, 3, [14, 9, 8], 126)}
+FORCE = {(32, 1009): (8, 3, [14, 9, 8], 126)}  # (mode 9 = mode 3 + non-temporal row loads, round 5: +1.3 % at config 4's batch, -2 % at 1 GiB: not shipped)
 
 
 def is_prime(n):
