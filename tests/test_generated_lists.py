@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 def test_rader_lists_match_the_generator():
     import gen_rader_kernels as gen
 
-    assert not (gen.ALT or gen.ALT2 or gen.ALT3 or gen.ALT5 or gen.ALT6), "RADER_ALT must not be set while testing"
+    assert not (gen.ALT or gen.ALT2 or gen.ALT3 or gen.ALT5 or gen.ALT6 or gen.X31_ALL or gen.X31_SLP or gen.X31_M5), "RADER_ALT / RADER_X31* must not be set while testing"
     s13 = set(gen.g.smooth(4096, [2, 3, 5, 7, 11, 13]))
     primes13 = [p for p in range(17, 4097) if gen.is_prime(p) and (p - 1) in s13]
     for tag, ty, prec in (("f32", "float", 32), ("f64", "double", 64)):
@@ -26,7 +26,10 @@ def test_rader_lists_match_the_generator():
                 assert int(m.group(6)) not in have, "a prime has one body"
                 have[int(m.group(6))] = (int(m.group(3)), int(m.group(4)), [int(v) for v in m.group(5).split(",")])
                 # the bodies measured faster without the SLP vectoriser sit in the units the Makefile compiles with -fno-slp-vectorize
-                assert (prec == 32 and (int(m.group(6)) in gen.NOSLP_F32 or int(m.group(6)) in gen.MODE3_F32)) == unit.startswith("ns"), (tag, unit, m.group(6))
+                # (round 5: so do the 31-smooth primes taken from Bluestein, but for the few that measured faster with the vectoriser)
+                q = int(m.group(6))
+                x31_noslp = (32, q) in gen.EXTRA31_R5 and (32, q) not in gen.EXTRA31_R2 and q not in gen.X31_SLP_F32
+                assert (prec == 32 and (q in gen.NOSLP_F32 or q in gen.MODE3_F32 or x31_noslp)) == unit.startswith("ns"), (tag, unit, m.group(6))
         assert sorted(have) == primes, (tag, sorted(set(primes) ^ set(have)))
         mk = open(os.path.join(ROOT, "rustfft_amd", "csrc", "Makefile")).read()
         for unit in units:

@@ -620,6 +620,40 @@ def test_every_prime_below_1000_and_prime_radices(planners, oracle, dtype):
         check_fft_algorithm(fft, n, 0, reference=oracle.plan(dtype, n, 0), n=3)
 
 
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_rader_bodies_of_the_31_smooth_primes_on_the_device(planners, oracle, dtype):
+    """Round 5: every prime <= 4096 that moved from the one-kernel Bluestein to a compiled Rader body with prime-radix sub-passes
+    (tools/gen_rader_kernels.py EXTRA31_R5: 89 Complex<f32> / 77 Complex<f64>), both directions, one full workgroup of rows and a ragged
+    one, against numpy in float64; every fourth prime also element-wise against the reference's plan (tests/accuracy.rs bar)."""
+    import re
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_rader_kernels as gen
+
+    planner = planners[np.dtype(dtype)]
+    prec = 32 if dtype == np.complex64 else 64
+    new = sorted(p for (pr, p) in gen.EXTRA31_R5 if pr == prec and (pr, p) not in gen.EXTRA31_R2)
+    assert len(new) == (89 if prec == 32 else 77)
+    worst = 0.0
+    for i, p in enumerate(new):
+        for d in (0, 1):
+            fft = planner.plan_fft(p, d)
+            assert fft.describe().startswith("rader<%d," % (p - 1)), (p, fft.describe())
+            rows = int(re.search(r"xF(\d+)", fft.describe()).group(1)) + 3
+            x = random_signal(rows * p, dtype, seed=p)
+            y = x.copy()
+            fft.process(y)
+            err = rel_l2(y, numpy_fft(x, p, d == 1))
+            worst = max(worst, err)
+            assert err < REL[np.dtype(dtype)], (p, d, err, fft.describe())
+            if i % 4 == 0:
+                want = x.copy()
+                oracle.plan(dtype, p, d).process(want)
+                assert compare_vectors(want, y), (p, d, fft.describe())
+    print(f"31-smooth Rader primes {np.dtype(dtype).name}: {len(new)} primes x 2 directions, worst rel L2 vs numpy c128 {worst:.2e}")
+
+
 def test_repeatability_bit_for_bit(planners):
     """A transform is a pure function of its input: five runs of every kernel family on the same HBM-resident input must
     agree bit for bit.  A write-write or read-write race between threads (round 2: the Rader X[0] slot) shows up here as
@@ -627,7 +661,8 @@ def test_repeatability_bit_for_bit(planners):
     import torch
 
     lengths = [17, 127, 257, 541, 911, 1009, 1201, 2311, 4051,     # Rader family (all three body forms)
-               719, 1019, 4093, 4099, 7919, 10007, 65537,            # Bluestein: one kernel, split one kernel, fused multi-kernel
+               59, 1013, 1117, 2053, 4093,                           # Rader over prime-radix sub-passes (round 5: the 31-smooth primes)
+               719, 1019, 4091, 4099, 7919, 10007, 65537,            # Bluestein: one kernel, split one kernel, fused multi-kernel
                289, 899, 1200, 4096, 5000, 1 << 14, 25000,           # compiled schedules incl. prime radices, whole-row split kernels
                4836, 20449, 44100, 1 << 17, 1 << 20, 1 << 22]        # run-time scheduled, general and power-of-two column tiles
     for dtype, tdtype in ((np.complex64, torch.complex64), (np.complex128, torch.complex128)):

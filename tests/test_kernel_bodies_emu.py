@@ -4,6 +4,7 @@
 patterns, twiddle tables, buffer rotation and the API semantics against the oracle; it says nothing about
 performance and is never loaded by the product."""
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -458,6 +459,38 @@ def test_compiled_rader_bodies_every_form(emu_planner, oracle, dtype):
             fft = planner.plan_fft(p, d)
             assert fft.describe().startswith("rader<%d," % (p - 1)) and fft.describe().endswith(form), (p, fft.describe())
             check_fft_algorithm(fft, p, d, reference=oracle.plan(dtype, p, d), n=11)  # 11 rows: one full group of 8 and a ragged one
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_rader_bodies_of_the_31_smooth_primes(emu_planner, oracle, dtype):
+    """Round 5: the primes <= 4096 whose p - 1 has a prime factor 17 .. 31 and that measured faster through a compiled Rader body (prime-radix
+    sub-passes in the inner transforms) than through the one-kernel Bluestein: 89 Complex<f32> / 77 Complex<f64> more than rounds 2 - 4 had
+    (tools/gen_rader_kernels.py EXTRA31_R5).  The reference's planner takes Rader for none of them (src/plan.rs:636-665: Bluestein when p - 1 has
+    a factor above 23 ... its own inner-length rule) -- the result must still be the reference's, so a sample of every form (side by side, with
+    the register hand-over, compiled with / without the SLP vectoriser) runs both directions, ragged batch, against the reference's plan; the
+    three primes with no side-by-side layout (929, 1217, 3041) stay with Bluestein."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_rader_kernels as gen
+
+    planner = emu_planner(dtype)
+    prec = 32 if dtype == np.complex64 else 64
+    new = sorted(p for (pr, p) in gen.EXTRA31_R5 if pr == prec and (pr, p) not in gen.EXTRA31_R2)
+    assert len(new) == (89 if prec == 32 else 77)
+    for p in new:  # every one of them plans as a Rader body of its measured form
+        want = "m5" if (prec, p) in gen.MODE5 else "m1"
+        d = planner.plan_fft(p, 0).describe()
+        assert d.startswith("rader<%d," % (p - 1)) and d.endswith(want), (p, d)
+    for p in (929, 1217, 3041):
+        assert planner.plan_fft(p, 0).describe().startswith("bluestein<"), p
+    sample = ([47, 59, 103, 523, 1013, 1021, 1117, 1451, 2053, 3469, 4093] if prec == 32 else [47, 137, 191, 457, 1013, 1103, 2143, 3313, 4093])
+    assert set(sample) <= set(new)
+    for p in sample:
+        for d in (0, 1):
+            fft = planner.plan_fft(p, d)
+            rows = int(re.search(r"xF(\d+)", fft.describe()).group(1))  # rows side by side in one workgroup
+            check_fft_algorithm(fft, p, d, reference=oracle.plan(dtype, p, d), n=rows + 3)  # one full workgroup and a ragged one
 
 
 def _thirteen_smooth(limit):

@@ -87,6 +87,23 @@ WIDE2_ROWS = ({(32, p) for p in (701, 727, 757, 881, 883, 1297)} |
 # Bluestein has to pad 2p - 1 up to 5120 or 6144
 EXTRA31 = ({(32, p) for p in (137, 647, 683, 2089, 2143, 2857)} |
            {(64, p) for p in (613, 2053, 2129, 2281, 2393, 2437, 2531, 2843, 3469, 3571, 3673, 3877, 3911)})
+X31_SLP = os.environ.get("RADER_X31_SLP") == "1"  # ... with the SLP vectoriser (the standard units)
+X31_M5 = os.environ.get("RADER_X31_M5") == "1"  # ... with the register hand-over (MODE 5)
+X31_ALL = os.environ.get("RADER_X31") == "all"  # experiment (round 5): EVERY prime <= 4096 with a 31-smooth p - 1 as a Rader body (f32: in the no-SLP units)
+if X31_ALL:
+    _s13 = set(g.smooth(4096, [2, 3, 5, 7, 11, 13]))
+    _s31 = set(g.smooth(4096, [2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31])) - _s13
+    EXTRA31 = EXTRA31 | {(pr, p) for pr in (32, 64) for p in range(17, 4097) if (p - 1) in _s31 and all(p % q for q in range(2, int(p ** 0.5) + 1))}
+# Round 5: all 99 re-measured (RADER_X31=all build against the shipped library, one process, two runs, profiles/r5/ab_x31_*.jsonl) -- the
+# side-by-side bodies batch their row loads since round 3 and the Complex<f32> ones compile without the SLP vectoriser: 90 of 93 / 75 of 86
+# now beat the one-kernel Bluestein (median +35 % / +31 %, up to +83 % / +114 %); with the register hand-over (MODE 5, RADER_X31_M5=1) where
+# that measured > 3 % faster and, for six f32 primes, WITH the vectoriser (RADER_X31_SLP=1: median -10 %, these +8 .. 19 %) the lists below
+# ship (89 / 77 primes; 929, 1217, 3041 -- no side-by-side layout fits, MODE 0 -- lose 28 - 51 % and stay with Bluestein)
+EXTRA31_R5 = ({(32, p) for p in (47, 59, 103, 139, 191, 229, 233, 239, 277, 307, 311, 349, 373, 409, 419, 443, 457, 461, 523, 571, 599, 613, 691, 761, 829, 919, 953, 967, 1013, 1021, 1103, 1117, 1123, 1151, 1277, 1289, 1303, 1327, 1361, 1381, 1427, 1429, 1451, 1483, 1531, 1567, 1597, 1613, 1657, 1667, 1741, 1861, 1871, 1901, 1933, 1973, 2053, 2129, 2281, 2347, 2357, 2381, 2393, 2437, 2531, 2551, 2729, 2791, 2843, 2851, 2927, 3037, 3061, 3079, 3163, 3191, 3221, 3307, 3313, 3469, 3571, 3673, 3727, 3877, 3907, 3911, 4003, 4049, 4093)} |
+              {(64, p) for p in (47, 59, 103, 137, 139, 191, 229, 239, 277, 307, 311, 349, 373, 409, 419, 443, 457, 523, 571, 599, 647, 691, 761, 829, 919, 953, 967, 1013, 1021, 1103, 1117, 1123, 1151, 1277, 1289, 1327, 1361, 1381, 1427, 1429, 1451, 1483, 1531, 1567, 1597, 1613, 1657, 1667, 1741, 1861, 1871, 1901, 1933, 1973, 2089, 2143, 2347, 2357, 2381, 2551, 2729, 2791, 2851, 2857, 2927, 3037, 3061, 3079, 3163, 3191, 3221, 3307, 3313, 3727, 3907, 4049, 4093)})
+X31_SLP_F32 = {59, 523, 1117, 1451, 1741}  # the new Complex<f32> bodies that keep the SLP vectoriser (the standard units)
+EXTRA31_R2 = set(EXTRA31)
+EXTRA31 = EXTRA31 | EXTRA31_R5
 # (the sweep listed 14 / 17; the Bluestein bodies were then rescheduled -- 1280 and 5120 run 22 % faster -- and the one-process
 # confirmation, profiles/r2/rader_choices_confirm_*.jsonl, kept the 6 / 13 that still win by > 3 %)
 # f32 bodies whose tables spill at MODE 2's 168 VGPRs and run 5 - 23 % faster at MODE 4's 256 (profiles/r2/rader_ab4_*.json; 1301
@@ -170,6 +187,8 @@ ALT5 = os.environ.get("RADER_ALT") == "5"  # experiment 5: every side-by-side bo
 # pass over the primes still on MODE 1, rader_mode5_ab2_*.jsonl, added 2 f32 / 13 f64 more at +4 .. 9 %)
 MODE5 = ({(32, p) for p in (37, 41, 43, 53, 67, 71, 101, 109, 127, 131, 137, 151, 199, 281, 331, 521, 677, 751, 859, 2003, 2143, 2647, 2801, 2857, 2917, 2971, 3001, 3851, 4001, 4057)} |
          {(64, p) for p in (41, 43, 53, 71, 113, 127, 131, 193, 197, 211, 251, 331, 337, 379, 397, 463, 487, 491, 521, 541, 547, 631, 641, 701, 751, 769, 911, 1249, 1321, 1601, 1621, 1801, 1951, 2003, 2113, 2251, 2281, 2311, 2377, 2549, 2647, 2689, 2731, 2801, 2861, 2917, 2971, 3001, 3121, 3169, 3251, 3329, 3389, 3529, 3631, 3697, 3851, 4001)})
+# round 5, the 31-smooth primes (profiles/r5/ab_x31_m5_*.jsonl: > 3 % in both runs; family median +2.5 % / -0.8 %)
+MODE5 = MODE5 | {(32, p) for p in (103, 139, 229, 239, 311, 349, 443, 571, 691, 829, 953, 967, 1013, 1021, 1123, 1151, 1289, 1361, 1381, 1429, 1871, 1933, 2053, 2129, 2347, 2437, 2531, 2927, 3037, 3061, 3191, 3221, 3469, 3571, 3727, 3877, 4049)} | {(64, p) for p in (137, 191, 229, 277, 311, 409, 457, 571, 761, 1103, 1361, 1597, 2089, 2143, 2357, 2551, 2851, 3163, 3313)}
 
 
 # Complex<f32> bodies that run >= 3 % faster compiled WITHOUT the SLP vectoriser (one-process A/B of two builds over every prime,
@@ -186,7 +205,7 @@ def main():
         modes = {}
         primes = sorted([p for p in primes13 if (prec, p) not in SKIP] + [p for (pr, p) in EXTRA31 if pr == prec])
         alt6 = {p for p in primes if (ALT6 or p in MODE3_F32) and prec == 32 and choose(p, prec)[1] in (2, 4)}
-        noslp = [p for p in primes if prec == 32 and (p in NOSLP_F32 or p in alt6)]
+        noslp = [p for p in primes if prec == 32 and (p in NOSLP_F32 or p in alt6 or (not X31_SLP and (32, p) in EXTRA31 and (32, p) not in EXTRA31_R2 and p not in X31_SLP_F32))]
         primes = [p for p in primes if p not in noslp]
         units = [(str(ci), primes[ci::NFILES], "") for ci in range(NFILES)]
         if noslp:
@@ -195,7 +214,7 @@ def main():
             lines = []
             for p in plist:
                 f, mode, rad, tpf = choose(p, prec)
-                if mode == 1 and (ALT5 or (prec, p) in MODE5) and len(rad) >= 2:
+                if mode == 1 and (ALT5 or (prec, p) in MODE5 or (X31_M5 and (prec, p) in EXTRA31 and (prec, p) not in EXTRA31_R2)) and len(rad) >= 2:
                     mode = 5
                 if p in alt6:
                     mode = 3
