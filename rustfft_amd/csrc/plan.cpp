@@ -158,6 +158,22 @@ void ensure_registry() {
         register_smooth4_f64_5(r);
         register_smooth4_f64_6(r);
         register_smooth4_f64_7(r);
+        register_smooth5_f32_ns0(r);
+        register_smooth5_f32_ns1(r);
+        register_smooth5_f32_ns2(r);
+        register_smooth5_f32_ns3(r);
+        register_smooth5_f32_ns4(r);
+        register_smooth5_f32_ns5(r);
+        register_smooth5_f32_ns6(r);
+        register_smooth5_f32_ns7(r);
+        register_smooth5_f64_0(r);
+        register_smooth5_f64_1(r);
+        register_smooth5_f64_2(r);
+        register_smooth5_f64_3(r);
+        register_smooth5_f64_4(r);
+        register_smooth5_f64_5(r);
+        register_smooth5_f64_6(r);
+        register_smooth5_f64_7(r);
         register_smooth3_f32_0(r);
         register_smooth3_f32_1(r);
         register_smooth3_f32_2(r);

@@ -138,6 +138,22 @@ void register_smooth4_f64_4(std::vector<KernelEntry>&);
 void register_smooth4_f64_5(std::vector<KernelEntry>&);
 void register_smooth4_f64_6(std::vector<KernelEntry>&);
 void register_smooth4_f64_7(std::vector<KernelEntry>&);
+void register_smooth5_f32_ns0(std::vector<KernelEntry>&);  // round 5: lengths with a prime factor 17 .. 31 above the smooth3 limits, up to 8192 (tools/gen_smooth_kernels.py main_primes_big)
+void register_smooth5_f32_ns1(std::vector<KernelEntry>&);
+void register_smooth5_f32_ns2(std::vector<KernelEntry>&);
+void register_smooth5_f32_ns3(std::vector<KernelEntry>&);
+void register_smooth5_f32_ns4(std::vector<KernelEntry>&);
+void register_smooth5_f32_ns5(std::vector<KernelEntry>&);
+void register_smooth5_f32_ns6(std::vector<KernelEntry>&);
+void register_smooth5_f32_ns7(std::vector<KernelEntry>&);
+void register_smooth5_f64_0(std::vector<KernelEntry>&);
+void register_smooth5_f64_1(std::vector<KernelEntry>&);
+void register_smooth5_f64_2(std::vector<KernelEntry>&);
+void register_smooth5_f64_3(std::vector<KernelEntry>&);
+void register_smooth5_f64_4(std::vector<KernelEntry>&);
+void register_smooth5_f64_5(std::vector<KernelEntry>&);
+void register_smooth5_f64_6(std::vector<KernelEntry>&);
+void register_smooth5_f64_7(std::vector<KernelEntry>&);
 
 // generated: compiled schedules for the lengths <= 2048 (f64: 1024) with a prime factor 17 .. 31 (tools/gen_smooth_kernels.py main_primes)
 void register_smooth3_f32_0(std::vector<KernelEntry>&);

@@ -68,6 +68,8 @@ def test_smooth_units_match_the_generator_and_the_noslp_choice():
                     [x for x in gs.smooth(32768, [2, 3, 5, 7]) if x > 16384 and (x & (x - 1)) and gs.big_schedule32(x)]),
     }
     want["smooth4"] = gs.big13_sizes((16, 32)) + gs.big13_sizes32()  # round 5: the 13-smooth lengths in (4096, 32768] with a factor 11 / 13
+    want["smooth5"] = gs.big31_sizes(32)  # round 5: the lengths in (4096, 8192] with a prime factor 17 .. 31
+    assert len(want["smooth5"]) == 351
     csrc = os.path.join(ROOT, "rustfft_amd", "csrc")
     for fam, sizes in want.items():
         seen = {}
@@ -83,7 +85,20 @@ def test_smooth_units_match_the_generator_and_the_noslp_choice():
                 seen[n] = unit
         assert sorted(seen) == sorted(sizes), (fam, sorted(set(seen) ^ set(sizes))[:10])
         ns = {n for n, u in seen.items() if u.startswith("ns")}
+        if fam == "smooth5":  # all of them: the prime-radix and 32-value kernels are the ones the vectoriser costs most (no per-length choice taken)
+            assert ns == set(sizes)
+            continue
         assert ns == set(choice.get(fam, [])) & set(sizes), (fam, sorted(ns ^ (set(choice.get(fam, [])) & set(sizes)))[:10])
+    # Complex<f64> smooth5 (the f32 loop above reads the f32 units only): every length once, the plain exchange up to 4096, split above
+    seen = {}
+    for fn in sorted(os.listdir(csrc)):
+        if re.fullmatch(r"kernels_smooth5_f64_\d+\.hip", fn):
+            assert fn.replace(".hip", ".o") in mk and fn.replace(".hip", "") not in noslp_line
+            for km in re.finditer(r"MI_K1X?\(double, 64, 1, (true|false), (?:\d+, \"\w*\", )?(\d+),", open(os.path.join(csrc, fn)).read()):
+                n = int(km.group(2))
+                assert n not in seen and (km.group(1) == "true") == (n > 4096), n
+                seen[n] = fn
+    assert sorted(seen) == gs.big31_sizes(64) and len(seen) == 576
 
 
 def test_general_tile_units_match_the_noslp_choice():

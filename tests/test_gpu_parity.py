@@ -462,7 +462,8 @@ def test_general_column_tile_passes(planners, oracle, dtype):
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_single_kernel_above_4096(planners, oracle, dtype):
     """2^13 .. 2^15 (f32; 2^14 in f64) and every generated 7-smooth length in (4096, 16384] -- round 5: and every 13-smooth one with a factor
-    11 / 13 (kernels_smooth4_*: 264 lengths in f32, 173 in f64, two general column-tile passes until then) -- run as one split-exchange kernel:
+    11 / 13 (kernels_smooth4_*: 264 lengths in f32, 173 in f64, two general column-tile passes until then) -- run as one split-exchange kernel
+    (and the kernels_smooth5_* lengths: prime radices 17 .. 31, 351 f32 / 576 f64 lengths, f64 below 4096 through the plain exchange):
     vs the oracle's plan (Radix4 / RadixN, src/plan.rs:508-607) under the reference tolerance and vs numpy in float64."""
     import glob
     import re
@@ -473,7 +474,10 @@ def test_single_kernel_above_4096(planners, oracle, dtype):
     sizes = [8192, 16384] + ([32768] if dtype == np.complex64 else [])
     for f in glob.glob(os.path.join(root, "rustfft_amd", "csrc", "kernels_smooth2_%s_*.hip" % tag)) + glob.glob(os.path.join(root, "rustfft_amd", "csrc", "kernels_smooth4_%s_*.hip" % tag)):
         sizes += [int(m) for m in re.findall(r'MI_K1X?\(\w+, \d+, 1, true, (?:\d+, "\w*", )?(\d+),', open(f).read())]
-    assert len(sizes) > 280 and 5005 in sizes and 13312 in sizes
+    # round 5, late: the lengths with a prime factor 17 .. 31 above the smooth3 limits (kernels_smooth5_*: f32 (4096, 8192], f64 (2048, 8192]; Bluestein until then)
+    for f in glob.glob(os.path.join(root, "rustfft_amd", "csrc", "kernels_smooth5_%s_*.hip" % tag)):
+        sizes += [int(m) for m in re.findall(r'MI_K1X?\(\w+, \d+, 1, (?:true|false), (?:\d+, "\w*", )?(\d+),', open(f).read())]
+    assert len(sizes) > 280 + (351 if tag == "f32" else 576) and 5005 in sizes and 13312 in sizes and 4352 in sizes and 8184 in sizes
     for n in sorted(sizes):
         d = n % 2
         fft = planner.plan_fft(n, d)
@@ -501,13 +505,16 @@ def test_runtime_scheduled_kernels(planners, oracle, dtype):
             fft = planner.plan_fft(n, d)
             assert "k2gfirst" in fft.describe(), (n, fft.describe())
             check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=3)
-    for n in [4352, 4836, 6448]:  # a prime factor 17 .. 31 above the compiled set: AUTO takes the one-kernel Bluestein (measured
-        for d in (0, 1):          # faster, profiles/r2/heavy_vs_bluestein_above_4096.txt); a host planner's MixedRadix recipe gets the HEAVY kernel
-            assert "bluestein<" in planner.plan_fft(n, d).describe()
+    for n in [4352, 4836, 6448]:  # a prime factor 17 .. 31 above 4096: compiled whole-row schedules since round 5 (kernels_smooth5_*; rounds 2 - 4: AUTO took the
+        for d in (0, 1):          # one-kernel Bluestein, a host planner's MixedRadix recipe the run-time scheduled HEAVY kernel); both entry points get them
+            assert planner.plan_fft(n, d).describe().startswith("k1<%d," % n)
             fft = planner.plan_fft_with(n, d, algorithm=rustfft_amd.ALGO_MIXED_RADIX)
-            assert "dyn_k1" in fft.describe(), (n, fft.describe())
+            assert fft.describe().startswith("k1<%d," % n), (n, fft.describe())
             check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=3)
-    if dtype == np.complex64:  # compiled prime-radix schedules reach 4096 in f32 (2048 in f64)
+    for n in [8211, 9248]:  # ... and above 8192 Bluestein (two kernels / fused multi-kernel: the inner length exceeds one workgroup)
+        assert "bluestein" in planner.plan_fft(n, 0).describe()
+        check_fft_algorithm(planner.plan_fft(n, 0), n, 0, reference=oracle.plan(dtype, n, 0), n=3)
+    if True:  # compiled prime-radix schedules: both precisions up to 8192 since round 5 (before: 4096 in f32, 2048 in f64)
         for n in [2057, 2108, 3553, 3910, 4048, 4092]:
             for d in (0, 1):
                 fft = planner.plan_fft(n, d)

@@ -393,6 +393,9 @@ def test_single_kernel_above_4096(emu_planner, oracle, dtype):
     planner = emu_planner(dtype)
     sizes = [4116, 4375, 5000, 6561, 8192, 10000, 12288, 16384] + ([14406, 15625, 16200, 19683, 25000, 32768] if dtype == np.complex64 else [])
     sizes += [4125, 4459, 5005, 9009, 13312] + ([15015, 16380, 16562, 20449, 26325] if dtype == np.complex64 else [])  # round 5: factors 11 / 13 (kernels_smooth4_*; f32 also with 32 values per thread, up to 32768)
+    # round 5, late: lengths with a prime factor 17 .. 31 above the smooth3 limits (kernels_smooth5_*: every prime radix, 32 values per thread in
+    # f32, f64 through the plain exchange up to 4096 and the split one above); Bluestein until then
+    sizes += [4352, 4495, 5239, 6800, 7429, 8160, 8184] + ([2052, 2185, 3400, 3553, 4080] if dtype == np.complex128 else [])
     for n in sizes:
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
@@ -661,8 +664,8 @@ def test_random_recipe_trees(emu_planner):
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_prime_radices_17_to_31(emu_planner, oracle, dtype):
     """The reference's Butterfly17 .. Butterfly31 (src/algorithm/butterflies.rs:1582-6241) as in-register prime radices:
-    lengths with such a factor run as mixed-radix kernels -- compiled schedules up to 4096 (f64: 2048), the run-time
-    scheduled HEAVY kernel above 4096 -- and no longer through Bluestein."""
+    lengths with such a factor run as mixed-radix kernels -- compiled schedules up to 8192 (rounds 2 - 4: 4096, f64 2048; the
+    one-kernel Bluestein above), the run-time scheduled HEAVY kernel on a host planner's request -- and no longer through Bluestein."""
     planner = emu_planner(dtype)
     for n in (17, 19, 23, 29, 31, 34, 51, 93, 289, 323, 437, 899, 961, 992, 1023):
         for d in (0, 1):
@@ -674,14 +677,18 @@ def test_prime_radices_17_to_31(emu_planner, oracle, dtype):
     for n in (1088, 1734, 2465, 3553, 4092, 4352, 6448):
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
-            if n <= (4096 if dtype == np.complex64 else 2048):
-                assert fft.describe().startswith("k1<%d," % n), (n, fft.describe())  # compiled up to 4096 in f32, 2048 in f64
-            elif n <= 8192:  # the one-kernel Bluestein measured faster than the run-time scheduled HEAVY kernel ...
-                assert "bluestein" in fft.describe(), (n, fft.describe())
-                fft = planner.plan_fft_with(n, d, algorithm=rustfft_amd.ALGO_MIXED_RADIX)  # ... which a host planner can still ask for
-            assert "dyn_k1" in fft.describe() or fft.describe().startswith("k1<"), (n, fft.describe())
+            assert fft.describe().startswith("k1<%d," % n), (n, fft.describe())  # compiled up to 8192 (round 5: kernels_smooth5_*)
             check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=2)
-    assert "bluestein" in planner.plan_fft(4913, 0).describe()  # 17^3: three 17-point sub-passes need 289 threads per row
+    for n in (8211, 9248):  # 3 x 7 x 17 x 23, 2^5 x 17^2: above the compiled range: Bluestein (the run-time scheduled HEAVY kernel ends at 8192 and measured slower than it there)
+        fft = planner.plan_fft(n, 0)
+        assert "bluestein" in fft.describe(), (n, fft.describe())
+        check_fft_algorithm(fft, n, 0, reference=oracle.plan(dtype, n, 0), n=2)
+    fft = planner.plan_fft_with(6448, 0, algorithm=rustfft_amd.ALGO_MIXED_RADIX)  # a host planner's MixedRadix request: a mixed-radix kernel (compiled now; the run-time scheduled one before)
+    assert fft.describe().startswith("k1<6448,") or "dyn_k1" in fft.describe(), fft.describe()
+    check_fft_algorithm(fft, 6448, 0, reference=oracle.plan(dtype, 6448, 0), n=2)
+    fft = planner.plan_fft(4913, 0)  # 17^3: three 17-point sub-passes on 289 threads per row (Bluestein until round 5)
+    assert fft.describe().startswith("k1<4913, 289, 17, 17, 17>"), fft.describe()
+    check_fft_algorithm(fft, 4913, 0, reference=oracle.plan(dtype, 4913, 0), n=2)
 
 
 def test_pair_fused_column_tiles(emu_tuning_planner, oracle):

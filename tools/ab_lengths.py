@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--gib", type=float, default=0.5)
     ap.add_argument("--check", action="store_true", help="also compare the two builds' results on four rows (relative L2 of b against a)")
     ap.add_argument("--no-trim", action="store_true", help="keep every plan's workspace (what this tool did before round 4's last hour: a sweep over hundreds of multi-pass lengths then runs the device out of memory)")
+    ap.add_argument("--a-algo", default="", choices=["", "bluestein"], help="plan side a through the host-planner entry point with this algorithm (same library on both sides: AUTO's choice against Bluestein)")
     ap.add_argument("--all", action="store_true", help="time a length even when both builds describe the same plan (a changed kernel body keeps its name)")
     args = ap.parse_args()
     dt, tdt, esz = (np.complex64, torch.complex64, 8) if args.dtype == "f32" else (np.complex128, torch.complex128, 16)
@@ -57,6 +58,8 @@ def main():
         batch = x.numel() // n
         buf = x[: batch * n]
         ffts = [p.plan_fft_forward(n) for p in pl]
+        if args.a_algo == "bluestein":
+            ffts[0] = pl[0].plan_fft_with(n, 0, algorithm=rustfft_amd.ALGO_BLUESTEIN)
         if ffts[0].describe() == ffts[1].describe() and not args.all:
             continue
         diff = None

@@ -331,10 +331,57 @@ def main_primes(limits=(("f32", "float", 32, 8, 4096, 14), ("f64", "double", 64,
         print(len(sizes), "lengths with a factor 17 .. 31, <=", limit, tag)
 
 
+RADICES_BIG31 = sorted(set(RADICES_BIG13 + BIG_PRIMES), reverse=True)
+S5_LIMIT = 8192
+S5_FILES = 8
+
+
+def big31_sizes(prec):
+    """Round 5, late: the lengths with a prime factor 17 .. 31 ABOVE main_primes' limits -- Complex<f32> in (4096, 8192] (split exchange, 32 values
+    per thread, at most four sub-passes on at most 1024 threads), Complex<f64> in (2048, 4096] (the plain exchange, schedule31 as below 2048) and
+    in (4096, 8192] (split exchange).  They ran through Bluestein (inner length 5120 .. 16384: 0.15 - 0.2 of 8 TB/s)."""
+    s13 = set(smooth(S5_LIMIT, [2, 3, 5, 7, 11, 13]))
+    s31 = [x for x in smooth(S5_LIMIT, [2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31]) if x not in s13]
+    if prec == 32:
+        return [x for x in s31 if x > 4096 and big_schedule32(x, RADICES_BIG31)]
+    out = []
+    for x in s31:
+        if x <= 2048:
+            continue
+        r = schedule31(x, 32, 6)
+        if r and r[1] <= 1024:
+            out.append(x)
+    return out
+
+
+def main_primes_big():
+    """kernels_smooth5_*: see big31_sizes.  Complex<f32>: every unit is compiled without the SLP vectoriser (the prime-radix and the 32-value
+    kernels are the ones that lose most with it: smooth3 / smooth4 measurements)."""
+    for tag, ty, prec, esz in (("f32", "float", 32, 8), ("f64", "double", 64, 16)):
+        sizes = big31_sizes(prec)
+        for ci in range(S5_FILES):
+            lines = []
+            for n in sizes[ci::S5_FILES]:
+                if prec == 32:
+                    rad, tpf = big_schedule32(n, RADICES_BIG31)
+                else:
+                    rad, tpf = schedule31(n, 32, 6)
+                lines.append(k1_line(ty, prec, 1, "true" if n > 4096 else "false", n, tpf, rad))
+            unit = f"ns{ci}" if prec == 32 else str(ci)
+            path = os.path.join(ROOT, "rustfft_amd", "csrc", f"kernels_smooth5_{tag}_{unit}.hip")
+            with open(path, "w") as fh:
+                fh.write(f"// GENERATED by tools/gen_smooth_kernels.py — do not edit.  Single-kernel schedules for the lengths with a prime factor 17 .. 31\n"
+                         f"// in (4096, 8192] (Complex<f64>: (2048, 8192]; split exchange above 4096; unit {unit}), Complex<{ty}>.\n"
+                         '#include "launch.h"\nnamespace mi355 {\n'
+                         f"void register_smooth5_{tag}_{unit}(std::vector<KernelEntry>& reg) {{\n" + "\n".join(lines) + "\n}\n}  // namespace mi355\n")
+        print(len(sizes), "lengths with a factor 17 .. 31 above the smooth3 limits, <=", S5_LIMIT, tag)
+
+
 def main():
     main_big()
     main_big13()
     main_primes()
+    main_primes_big()
     sizes = [x for x in smooth(4096, [2, 3, 5, 7, 11, 13]) if x > 2 and (x & (x - 1)) and x != 1200]
     for tag, ty, prec, esz in (("f32", "float", 32, 8), ("f64", "double", 64, 16)):
         for ci, chunk in units_of("smooth", tag, sizes, NFILES):
