@@ -68,8 +68,8 @@ def test_smooth_units_match_the_generator_and_the_noslp_choice():
                     [x for x in gs.smooth(32768, [2, 3, 5, 7]) if x > 16384 and (x & (x - 1)) and gs.big_schedule32(x)]),
     }
     want["smooth4"] = gs.big13_sizes((16, 32)) + gs.big13_sizes32()  # round 5: the 13-smooth lengths in (4096, 32768] with a factor 11 / 13
-    want["smooth5"] = gs.big31_sizes(32)  # round 5: the lengths in (4096, 8192] with a prime factor 17 .. 31
-    assert len(want["smooth5"]) == 351
+    want["smooth5"] = gs.big31_sizes(32)  # round 5: the lengths in (4096, 16384] with a prime factor 17 .. 31
+    assert len(want["smooth5"]) == 351 + 526
     csrc = os.path.join(ROOT, "rustfft_amd", "csrc")
     for fam, sizes in want.items():
         seen = {}
@@ -98,7 +98,7 @@ def test_smooth_units_match_the_generator_and_the_noslp_choice():
                 n = int(km.group(2))
                 assert n not in seen and (km.group(1) == "true") == (n > 4096), n
                 seen[n] = fn
-    assert sorted(seen) == gs.big31_sizes(64) and len(seen) == 576
+    assert sorted(seen) == gs.big31_sizes(64) and len(seen) == 576 + 526
 
 
 def test_general_tile_units_match_the_noslp_choice():

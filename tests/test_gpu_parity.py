@@ -463,7 +463,7 @@ def test_general_column_tile_passes(planners, oracle, dtype):
 def test_single_kernel_above_4096(planners, oracle, dtype):
     """2^13 .. 2^15 (f32; 2^14 in f64) and every generated 7-smooth length in (4096, 16384] -- round 5: and every 13-smooth one with a factor
     11 / 13 (kernels_smooth4_*: 264 lengths in f32, 173 in f64, two general column-tile passes until then) -- run as one split-exchange kernel
-    (and the kernels_smooth5_* lengths: prime radices 17 .. 31, 351 f32 / 576 f64 lengths, f64 below 4096 through the plain exchange):
+    (and the kernels_smooth5_* lengths: prime radices 17 .. 31, 877 f32 / 1102 f64 lengths up to 16384, f64 below 4096 through the plain exchange):
     vs the oracle's plan (Radix4 / RadixN, src/plan.rs:508-607) under the reference tolerance and vs numpy in float64."""
     import glob
     import re
@@ -474,10 +474,10 @@ def test_single_kernel_above_4096(planners, oracle, dtype):
     sizes = [8192, 16384] + ([32768] if dtype == np.complex64 else [])
     for f in glob.glob(os.path.join(root, "rustfft_amd", "csrc", "kernels_smooth2_%s_*.hip" % tag)) + glob.glob(os.path.join(root, "rustfft_amd", "csrc", "kernels_smooth4_%s_*.hip" % tag)):
         sizes += [int(m) for m in re.findall(r'MI_K1X?\(\w+, \d+, 1, true, (?:\d+, "\w*", )?(\d+),', open(f).read())]
-    # round 5, late: the lengths with a prime factor 17 .. 31 above the smooth3 limits (kernels_smooth5_*: f32 (4096, 8192], f64 (2048, 8192]; Bluestein until then)
+    # round 5, late: the lengths with a prime factor 17 .. 31 above the smooth3 limits (kernels_smooth5_*: f32 (4096, 16384], f64 (2048, 16384]; Bluestein until then)
     for f in glob.glob(os.path.join(root, "rustfft_amd", "csrc", "kernels_smooth5_%s_*.hip" % tag)):
         sizes += [int(m) for m in re.findall(r'MI_K1X?\(\w+, \d+, 1, (?:true|false), (?:\d+, "\w*", )?(\d+),', open(f).read())]
-    assert len(sizes) > 280 + (351 if tag == "f32" else 576) and 5005 in sizes and 13312 in sizes and 4352 in sizes and 8184 in sizes
+    assert len(sizes) > 280 + (877 if tag == "f32" else 1102) and 5005 in sizes and 13312 in sizes and 4352 in sizes and 8184 in sizes and 16337 in sizes
     for n in sorted(sizes):
         d = n % 2
         fft = planner.plan_fft(n, d)
@@ -505,13 +505,13 @@ def test_runtime_scheduled_kernels(planners, oracle, dtype):
             fft = planner.plan_fft(n, d)
             assert "k2gfirst" in fft.describe(), (n, fft.describe())
             check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=3)
-    for n in [4352, 4836, 6448]:  # a prime factor 17 .. 31 above 4096: compiled whole-row schedules since round 5 (kernels_smooth5_*; rounds 2 - 4: AUTO took the
+    for n in [4352, 4836, 6448, 9248, 16337]:  # a prime factor 17 .. 31 above 4096: compiled whole-row schedules since round 5 (kernels_smooth5_*; rounds 2 - 4: AUTO took the
         for d in (0, 1):          # one-kernel Bluestein, a host planner's MixedRadix recipe the run-time scheduled HEAVY kernel); both entry points get them
             assert planner.plan_fft(n, d).describe().startswith("k1<%d," % n)
             fft = planner.plan_fft_with(n, d, algorithm=rustfft_amd.ALGO_MIXED_RADIX)
             assert fft.describe().startswith("k1<%d," % n), (n, fft.describe())
             check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=3)
-    for n in [8211, 9248]:  # ... and above 8192 Bluestein (two kernels / fused multi-kernel: the inner length exceeds one workgroup)
+    for n in [17408, 18496]:  # ... and above 16384 Bluestein (fused multi-kernel: the inner length exceeds one workgroup)
         assert "bluestein" in planner.plan_fft(n, 0).describe()
         check_fft_algorithm(planner.plan_fft(n, 0), n, 0, reference=oracle.plan(dtype, n, 0), n=3)
     if True:  # compiled prime-radix schedules: both precisions up to 8192 since round 5 (before: 4096 in f32, 2048 in f64)

@@ -395,7 +395,7 @@ def test_single_kernel_above_4096(emu_planner, oracle, dtype):
     sizes += [4125, 4459, 5005, 9009, 13312] + ([15015, 16380, 16562, 20449, 26325] if dtype == np.complex64 else [])  # round 5: factors 11 / 13 (kernels_smooth4_*; f32 also with 32 values per thread, up to 32768)
     # round 5, late: lengths with a prime factor 17 .. 31 above the smooth3 limits (kernels_smooth5_*: every prime radix, 32 values per thread in
     # f32, f64 through the plain exchange up to 4096 and the split one above); Bluestein until then
-    sizes += [4352, 4495, 5239, 6800, 7429, 8160, 8184] + ([2052, 2185, 3400, 3553, 4080] if dtype == np.complex128 else [])
+    sizes += [4352, 4495, 5239, 6800, 7429, 8160, 8184] + ([2052, 2185, 3400, 3553, 4080] if dtype == np.complex128 else []) + [8704, 9248, 12121, 16337, 16368]  # (the last five: the tier up to 16384)
     for n in sizes:
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
@@ -664,7 +664,7 @@ def test_random_recipe_trees(emu_planner):
 @pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
 def test_prime_radices_17_to_31(emu_planner, oracle, dtype):
     """The reference's Butterfly17 .. Butterfly31 (src/algorithm/butterflies.rs:1582-6241) as in-register prime radices:
-    lengths with such a factor run as mixed-radix kernels -- compiled schedules up to 8192 (rounds 2 - 4: 4096, f64 2048; the
+    lengths with such a factor run as mixed-radix kernels -- compiled schedules up to 16384 (rounds 2 - 4: 4096, f64 2048; the
     one-kernel Bluestein above), the run-time scheduled HEAVY kernel on a host planner's request -- and no longer through Bluestein."""
     planner = emu_planner(dtype)
     for n in (17, 19, 23, 29, 31, 34, 51, 93, 289, 323, 437, 899, 961, 992, 1023):
@@ -677,9 +677,9 @@ def test_prime_radices_17_to_31(emu_planner, oracle, dtype):
     for n in (1088, 1734, 2465, 3553, 4092, 4352, 6448):
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
-            assert fft.describe().startswith("k1<%d," % n), (n, fft.describe())  # compiled up to 8192 (round 5: kernels_smooth5_*)
+            assert fft.describe().startswith("k1<%d," % n), (n, fft.describe())  # compiled up to 16384 (round 5: kernels_smooth5_*)
             check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=2)
-    for n in (8211, 9248):  # 3 x 7 x 17 x 23, 2^5 x 17^2: above the compiled range: Bluestein (the run-time scheduled HEAVY kernel ends at 8192 and measured slower than it there)
+    for n in (17408, 18496):  # 2^10 x 17, 2^6 x 17^2: above the compiled range (16384): Bluestein (the run-time scheduled HEAVY kernel ends at 8192 and measured slower than it there)
         fft = planner.plan_fft(n, 0)
         assert "bluestein" in fft.describe(), (n, fft.describe())
         check_fft_algorithm(fft, n, 0, reference=oracle.plan(dtype, n, 0), n=2)

@@ -332,7 +332,7 @@ def main_primes(limits=(("f32", "float", 32, 8, 4096, 14), ("f64", "double", 64,
 
 
 RADICES_BIG31 = sorted(set(RADICES_BIG13 + BIG_PRIMES), reverse=True)
-S5_LIMIT = 8192
+S5_LIMIT = int(os.environ.get("S5_LIMIT", "16384"))  # (8192 in the first cut: profiles/r5/ab_smooth5_vs_bluestein_*; the tier above it added after that measurement)
 S5_FILES = 8
 
 
