@@ -1069,6 +1069,9 @@ template <class T> static int build_plan_t(Plan& plan) {
         // 1.1 - 1.3 TB/s up to 4096, 0.8 - 1.3 through the split exchange above), ahead of the multi-kernel forms.
         // Only the HEAVY set is planned this way: every 13-smooth length has a compiled schedule (<= 4096) or runs in
         // two to four column-tile passes (above), both faster than this kernel (1.0 - 1.8 TB/s).
+        // (round 5: the HEAVY set has compiled whole-row schedules up to 16384 now -- kernels_smooth5_* -- and this kernel's LDS layout ends at
+        // 8192, so no plan of the full build reaches it any more (tools/kernel_reachability.py); it still serves builds without the generated
+        // units, e.g. `make tuning-min`.)
         const bool heavy_loses = algo == MI355FFT_ALGO_AUTO && n <= 8192;
         if (dk && build_dyn_sched(n, 2 * sizeof(T), 0, ds) && ds.light == 2 && !heavy_loses) {
             if (dk->prepare()) return MI355FFT_ERR_HIP;

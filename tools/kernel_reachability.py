@@ -67,6 +67,8 @@ def main():
             if rc != 0:
                 return []
             out = [lib.mi355fft_plan_kernel_name(h, i).decode() for i in range(lib.mi355fft_plan_num_kernels(h))]
+            # the one-kernel Bluestein names get their form suffix at run time (launch.h bs_name: t1 / p<N>); the library's strings hold the stem
+            out = [re.sub(r"(>xF\d+s?)(?:t1)?(?:p\d+)?$", r"\1", v) if v.startswith("bluestein<") else v for v in out]
             lib.mi355fft_plan_destroy(h)
             return out
 
