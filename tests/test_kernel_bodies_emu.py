@@ -766,6 +766,38 @@ def test_two_columns_per_lane_tiles(emu_tuning_planner, oracle, order):
         os.environ.pop("MI355_EMU_ORDER", None)
 
 
+@pytest.mark.parametrize("order", ["", "reverse"])
+def test_every_late_round5_kernel_in_both_thread_orders(emu_planner, order):
+    """Every kernel the last third of round 5 added -- the 877 Complex<f32> / 1102 Complex<f64> whole-row schedules with a prime radix 17 .. 31
+    up to 16384 (kernels_smooth5_*) and the 89 / 77 Rader bodies of primes with a 31-smooth p - 1 (EXTRA31_R5) -- runs its body on the
+    emulator, in thread order and in reverse thread order (a race between threads of one phase shows up as a difference), two rows each, against
+    numpy in float64.  (The GPU suite runs the same lengths on the device.)"""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import gen_rader_kernels as gr
+    import gen_smooth_kernels as gs
+
+    if order:
+        os.environ["MI355_EMU_ORDER"] = order
+    try:
+        for dtype, prec, tol in ((np.complex64, 32, 5e-6), (np.complex128, 64, 1e-13)):
+            planner = emu_planner(dtype)
+            lengths = gs.big31_sizes(prec) + sorted(p for (pr, p) in gr.EXTRA31_R5 if pr == prec and (pr, p) not in gr.EXTRA31_R2)
+            assert len(lengths) == (877 + 89 if prec == 32 else 1102 + 77)
+            for n in lengths:
+                d = n % 2
+                fft = planner.plan_fft(n, d)
+                assert fft.describe().startswith(("k1<%d," % n, "rader<%d," % (n - 1))), (n, fft.describe())
+                x = random_signal(2 * n, dtype, seed=n)
+                y = x.copy()
+                fft.process(y)
+                assert rel_l2(y, numpy_fft(x, n, d == 1)) < tol, (n, d, order, fft.describe())
+    finally:
+        if order:
+            del os.environ["MI355_EMU_ORDER"]
+
+
 def test_thread_order_independence(emu_planner, oracle):
     """The emulator runs the threads of a phase one after another, so a race between threads of one phase is invisible to it
     unless the order changes: MI355_EMU_ORDER=reverse runs every phase from the last thread to the first.  Results must not
@@ -773,7 +805,9 @@ def test_thread_order_independence(emu_planner, oracle):
     whenever the schedule's LDS layout is unpadded -- invisible in thread order, wrong in reverse order, a coin toss on the GPU)."""
     lengths = [541, 911, 1009, 127, 257, 1201, 2311, 1297, 2003, 2081, 727, 2801, 613, 683, 2143, 2053, 719, 1019, 1200, 1281, 2311 + 2, 4096, 1 << 13, 1 << 16, 44100, 289, 992,
                # round 5: the Bluestein bodies with staged / prefetched sub-pass factors (2560, 3072, 3584, 6144, 8192) and whole-row kernels with the factors 11 / 13
-               1279, 1523, 1789, 3067, 4091, 5005, 9009]
+               1279, 1523, 1789, 3067, 4091, 5005, 9009,
+               # round 5, late: Rader bodies over prime-radix sub-passes (plain / hand-over) and the prime-radix whole-row kernels up to 16384
+               47, 1013, 1117, 2143, 4093, 3400, 4352, 7429, 16337]
     os.environ["MI355_EMU_ORDER"] = "reverse"
     try:
         for dtype in (np.complex64, np.complex128):
