@@ -767,28 +767,39 @@ def test_two_columns_per_lane_tiles(emu_tuning_planner, oracle, order):
 
 
 @pytest.mark.parametrize("order", ["", "reverse"])
-def test_every_late_round5_kernel_in_both_thread_orders(emu_planner, order):
-    """Every kernel the last third of round 5 added -- the 877 Complex<f32> / 1102 Complex<f64> whole-row schedules with a prime radix 17 .. 31
-    up to 16384 (kernels_smooth5_*) and the 89 / 77 Rader bodies of primes with a 31-smooth p - 1 (EXTRA31_R5) -- runs its body on the
-    emulator, in thread order and in reverse thread order (a race between threads of one phase shows up as a difference), two rows each, against
-    numpy in float64.  (The GPU suite runs the same lengths on the device.)"""
+def test_every_generated_kernel_in_both_thread_orders(emu_planner, order):
+    """Every GENERATED kernel -- the compiled whole-row schedules (kernels_smooth*_*: 2504 Complex<f32> / 2200 Complex<f64> lengths up to 32768 /
+    16384, among them the 877 / 1102 prime-radix schedules of kernels_smooth5_* that the last third of round 5 added) and the compiled Rader bodies
+    (kernels_rader_*: 231 / 225 primes, 89 / 77 of them new with a 31-smooth p - 1) -- runs its body on the emulator, in thread order and in
+    reverse thread order (a race between threads of one phase shows up as a difference), two rows each, against numpy in float64.  (The GPU suite
+    runs the same lengths on the device; the emulator takes about ten seconds for all of them.)"""
+    import glob
     import sys
 
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
     import gen_rader_kernels as gr
     import gen_smooth_kernels as gs
 
     if order:
         os.environ["MI355_EMU_ORDER"] = order
     try:
-        for dtype, prec, tol in ((np.complex64, 32, 5e-6), (np.complex128, 64, 1e-13)):
+        for dtype, prec, ty, tag, tol in ((np.complex64, 32, "float", "f32", 5e-6), (np.complex128, 64, "double", "f64", 1e-13)):
             planner = emu_planner(dtype)
-            lengths = gs.big31_sizes(prec) + sorted(p for (pr, p) in gr.EXTRA31_R5 if pr == prec and (pr, p) not in gr.EXTRA31_R2)
-            assert len(lengths) == (877 + 89 if prec == 32 else 1102 + 77)
-            for n in lengths:
+            whole = set()
+            for f in glob.glob(os.path.join(root, "rustfft_amd", "csrc", "kernels_smooth*_%s_*.hip" % tag)):
+                whole |= {int(m) for m in re.findall(r'MI_K1X?\(%s, \d+, \d+, (?:true|false), (?:\d+, "\w*", )?(\d+),' % ty, open(f).read())}
+            primes = set()
+            for f in glob.glob(os.path.join(root, "rustfft_amd", "csrc", "kernels_rader_%s_*.hip" % tag)):
+                primes |= {int(m) for m in re.findall(r"// p = (\d+)", open(f).read())}
+            late = set(gs.big31_sizes(prec)) | {p for (pr, p) in gr.EXTRA31_R5 if pr == prec and (pr, p) not in gr.EXTRA31_R2}
+            assert len(late) == (877 + 89 if prec == 32 else 1102 + 77) and late <= (whole | primes)
+            assert len(whole) == (2504 if prec == 32 else 2200) and len(primes) == (231 if prec == 32 else 225), (len(whole), len(primes))
+            for n in sorted(whole | primes):
                 d = n % 2
                 fft = planner.plan_fft(n, d)
-                assert fft.describe().startswith(("k1<%d," % n, "rader<%d," % (n - 1))), (n, fft.describe())
+                # (17 .. 31 have both a Rader body and a prime butterfly: AUTO takes the butterfly)
+                assert fft.describe().startswith("rader<%d," % (n - 1) if n in primes and n not in whole else "k1<%d," % n), (n, fft.describe())
                 x = random_signal(2 * n, dtype, seed=n)
                 y = x.copy()
                 fft.process(y)
