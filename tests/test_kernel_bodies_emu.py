@@ -809,6 +809,30 @@ def test_every_generated_kernel_in_both_thread_orders(emu_planner, order):
             del os.environ["MI355_EMU_ORDER"]
 
 
+def test_random_lengths_in_reverse_thread_order(emu_planner):
+    """400 lengths per precision drawn log-uniformly from 2 .. 120000 through AUTO (whole-row kernels, Rader bodies, one- / two-kernel and fused
+    Bluestein, general and prime column tiles, the multi-kernel Rader), the emulator running every phase from the last thread to the first,
+    two rows each against numpy in float64: the planner's choice for an arbitrary length must not depend on the order threads run in."""
+    rng = np.random.default_rng(20260925)
+    families = set()
+    os.environ["MI355_EMU_ORDER"] = "reverse"
+    try:
+        for dtype, tol in ((np.complex64, 5e-6), (np.complex128, 1e-13)):
+            planner = emu_planner(dtype)
+            for n in (int(v) for v in np.exp(rng.uniform(np.log(2), np.log(120000), 400))):
+                d = n % 2
+                fft = planner.plan_fft(n, d)
+                families.add(re.split(r"[<(]", fft.describe())[0])
+                x = random_signal(2 * n, dtype, seed=n)
+                y = x.copy()
+                fft.process(y)
+                assert rel_l2(y, numpy_fft(x, n, d == 1)) < tol, (n, d, fft.describe())
+                fft.trim_workspaces()
+    finally:
+        del os.environ["MI355_EMU_ORDER"]
+    assert {"k1", "rader", "bluestein", "bluestein_large", "k2gfirst", "k2rfirst"} <= families, families
+
+
 def test_thread_order_independence(emu_planner, oracle):
     """The emulator runs the threads of a phase one after another, so a race between threads of one phase is invisible to it
     unless the order changes: MI355_EMU_ORDER=reverse runs every phase from the last thread to the first.  Results must not
