@@ -271,15 +271,23 @@ int mi355fft_plan_set_fused(mi355fft_plan* plan, int mode);
 int mi355fft_plan_is_fused(const mi355fft_plan* plan);
 /* Waits between the workgroups of a fused launch are bounded; a wait that gave up (the device time-sliced between processes, a debugger
  * holding a workgroup) raises the plan's STICKY error word for that stream instead of hanging the GPU, and what that launch wrote is invalid.
- * The word is pinned host memory no launch clears, and the give-up cannot be missed (the reference's contract, src/lib.rs:184: an Fft is
- * never silently wrong):
+ * What a caller can and cannot see (the reference's contract, src/lib.rs:184: an Fft is never silently wrong):
+ *   - the DATA says so: a tile whose wait gave up multiplies the imaginary part of everything it stores by NaN, and every tile that reads such
+ *     a value (the second pass of that transform, a tile of another transform whose ring slot was overwritten early) produces NaN in all of
+ *     its outputs -- the rows the give-up touched come back as NaN, never as plausible numbers, whatever the caller does next;
  *   - host slices (mi355fft_process_*_host, mi355fft_multi_process_*_host): the affected rows are transformed again with one launch per
  *     pass before they are copied back -- the call succeeds with correct results;
- *   - device buffers: the NEXT mi355fft_process_*_dev / mi355fft_multi_process_*_dev on that plan and stream returns MI355FFT_ERR_HIP without
- *     running (mi355fft_last_error says why), as do mi355fft_multi_synchronize and mi355fft_plan_destroy; the caller re-runs the failed call
- *     (mi355fft_plan_set_fused(plan, 0) avoids a repeat).
+ *   - device buffers: an asynchronous entry point returns before the launch has run, so the CALL cannot fail.  The way to learn the verdict
+ *     is mi355fft_plan_synchronize(plan, stream) (multi-device plans: mi355fft_multi_synchronize): it waits for the stream and returns
+ *     MI355FFT_ERR_HIP when a fused launch of the plan on that stream gave up.  A caller that synchronises the stream itself
+ *     (hipStreamSynchronize, an event) must call mi355fft_plan_synchronize or mi355fft_plan_fused_status afterwards -- or look for NaN.  As a
+ *     fast path the NEXT mi355fft_process_*_dev / mi355fft_multi_process_*_dev on that plan and stream looks at the word when it is entered and
+ *     returns MI355FFT_ERR_HIP without running -- but it reads the word without waiting for the stream, so it only sees give-ups of launches
+ *     that have COMPLETED by then; mi355fft_plan_destroy / mi355fft_multi_plan_destroy drain the device and report what nobody asked about.
+ *     After a reported give-up the caller re-runs the failed call (mi355fft_plan_set_fused(plan, 0) avoids a repeat).
  * mi355fft_plan_fused_status synchronises `stream` and returns the word through *error_word (0 = every dependency of every fused launch since
  * the last report was met in time; also 0 when the plan never ran fused); reporting clears it. */
+int mi355fft_plan_synchronize(const mi355fft_plan* plan, void* stream);
 int mi355fft_plan_fused_status(const mi355fft_plan* plan, void* stream, unsigned* error_word);
 /* The bound: polls of about half a microsecond before a dependency wait gives up (default 2^21: about a second).  0 makes every wait that is
  * not already satisfied give up -- how the tests exercise the paths above on a healthy device; -1 does the same and, in addition, raises the

@@ -20,7 +20,7 @@ EXPORTS = [
     "mi355fft_multi_process_inplace_host", "mi355fft_multi_process_outofplace_host", "mi355fft_multi_process_immutable_host",
     "mi355fft_multi_process_inplace_dev", "mi355fft_multi_process_outofplace_dev", "mi355fft_multi_process_immutable_dev",
     "mi355fft_multi_synchronize", "mi355fft_device_cpulist", "mi355fft_multi_plan_shard_pinned", "mi355fft_multi_scatter_dev", "mi355fft_multi_gather_dev",
-    "mi355fft_measure_copy_ceiling", "mi355fft_plan_set_fused", "mi355fft_plan_is_fused", "mi355fft_plan_fused_status", "mi355fft_plan_set_fused_wait_limit", "mi355fft_plan_set_workspace_placement", "mi355fft_plan_set_chunk_batch", "mi355fft_plan_workspace_bytes", "mi355fft_plan_trim_workspaces", "mi355fft_strerror", "mi355fft_last_error", "mi355fft_version",
+    "mi355fft_measure_copy_ceiling", "mi355fft_plan_set_fused", "mi355fft_plan_is_fused", "mi355fft_plan_fused_status", "mi355fft_plan_synchronize", "mi355fft_plan_set_fused_wait_limit", "mi355fft_plan_set_workspace_placement", "mi355fft_plan_set_chunk_batch", "mi355fft_plan_workspace_bytes", "mi355fft_plan_trim_workspaces", "mi355fft_strerror", "mi355fft_last_error", "mi355fft_version",
 ]
 
 
@@ -90,6 +90,7 @@ def bind(lib):
     lib.mi355fft_plan_set_fused.argtypes = [vp, ci]
     lib.mi355fft_plan_is_fused.argtypes = [vp]
     lib.mi355fft_plan_fused_status.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_uint)]
+    lib.mi355fft_plan_synchronize.argtypes = [vp, vp]
     # (entry points newer than some A/B builds kept in rustfft_amd/lib: bound where present; tests/test_cabi_cpu.py holds the shipped
     # library to the full EXPORTS list)
     if hasattr(lib, "mi355fft_plan_set_fused_wait_limit"):

@@ -129,7 +129,14 @@ bool pin_this_thread(const std::string& cpulist) {
             }
         if (*p == ',') ++p;
     }
-    return n > 0 && sched_setaffinity(0, sizeof set, &set) == 0;
+    if (n == 0) return false;
+    // never leave the mask the thread inherited from its creator (taskset, numactl, a job scheduler's or an MPI rank's binding): the node's
+    // cores are intersected with it, and an empty intersection leaves the thread where it is
+    cpu_set_t inherited, both;
+    if (sched_getaffinity(0, sizeof inherited, &inherited) != 0) return false;
+    CPU_AND(&both, &set, &inherited);
+    if (CPU_COUNT(&both) == 0) return false;
+    return sched_setaffinity(0, sizeof both, &both) == 0;
 }
 
 // A staging context of the plan's pool for the duration of one host-slice call.
@@ -370,6 +377,13 @@ struct EventTracer : Tracer {
 };
 }  // namespace
 
+// a plan and the plans it runs through: the inner plan of the large Bluestein form, the balanced split a fused-resplit plan runs whenever a call
+// does not fuse (plan.cpp build_plan) -- a setting must reach whichever of them executes
+template <class Fn> static void for_each_subplan(Plan& p, Fn&& fn) {
+    fn(p);
+    if (p.inner) for_each_subplan(*p.inner, fn);
+    if (p.unfused_alt) for_each_subplan(*p.unfused_alt, fn);
+}
 extern "C" {
 
 int mi355fft_device_count(void) { return backend::device_count(); }
@@ -544,6 +558,18 @@ int mi355fft_plan_set_fused(mi355fft_plan* plan, int mode) {
     p.fuse_on = p.fused && (mode == 1 || (mode == -1 && p.fuse_default));
     return MI355FFT_OK;
 }
+// Stream-ordered completion WITH the verdict (the single-device twin of mi355fft_multi_synchronize): waits for everything enqueued on
+// `stream`, then reports a fused launch of this plan that gave up a dependency wait -- the one failure an asynchronous entry point cannot
+// return (include/mi355fft.h).  The word is reported once.
+int mi355fft_plan_synchronize(const mi355fft_plan* plan, void* stream) {
+    if (!plan) return set_err(MI355FFT_ERR_INVALID_ARG, "null plan");
+    Plan& p = const_cast<Plan&>(plan->p);
+    DeviceGuard dev(p.device);
+    if (backend::sync(stream)) return hip_err(MI355FFT_ERR_HIP);
+    if (fused_check(p, stream, true))
+        return set_err(MI355FFT_ERR_HIP, "a fused two-pass launch on this stream gave up waiting for a dependency; the rows it touched carry NaN imaginary parts and the results of that call are INVALID");
+    return MI355FFT_OK;
+}
 int mi355fft_plan_is_fused(const mi355fft_plan* plan) { return plan && plan->p.fuse_on && plan->p.fused ? 1 : 0; }
 int mi355fft_plan_fused_status(const mi355fft_plan* plan, void* stream, unsigned* error_word) {
     if (!plan || !error_word) return set_err(MI355FFT_ERR_INVALID_ARG, "null argument");
@@ -556,18 +582,17 @@ int mi355fft_plan_fused_status(const mi355fft_plan* plan, void* stream, unsigned
 }
 int mi355fft_plan_set_fused_wait_limit(mi355fft_plan* plan, int polls) {
     if (!plan || polls < -1) return set_err(MI355FFT_ERR_INVALID_ARG, "bad wait limit");
-    plan->p.fuse_spin_limit = polls;
-    if (plan->p.inner) plan->p.inner->fuse_spin_limit = polls;
+    for_each_subplan(plan->p, [&](Plan& q) { q.fuse_spin_limit = polls; });
     return MI355FFT_OK;
 }
 int mi355fft_plan_set_workspace_placement(mi355fft_plan* plan, int on) {
     if (!plan) return set_err(MI355FFT_ERR_INVALID_ARG, "null plan");
-    plan->p.place_workspace = on != 0;
+    for_each_subplan(plan->p, [&](Plan& q) { q.place_workspace = on != 0; });
     return MI355FFT_OK;
 }
 int mi355fft_plan_set_chunk_batch(mi355fft_plan* plan, size_t chunk_batch) {
     if (!plan) return set_err(MI355FFT_ERR_INVALID_ARG, "null plan");
-    plan->p.chunk_batch = chunk_batch;
+    for_each_subplan(plan->p, [&](Plan& q) { q.chunk_batch = chunk_batch; });
     return MI355FFT_OK;
 }
 
@@ -824,7 +849,18 @@ int mi355fft_multi_plan_create(size_t len, int direction, int precision, const m
     return MI355FFT_OK;
 }
 int mi355fft_multi_plan_destroy(mi355fft_multi_plan* plan) {
+    if (!plan) return MI355FFT_OK;
+    // as mi355fft_plan_destroy: the last chance to report a fused launch of a replica that gave up a wait and that nobody asked about
+    unsigned word = 0;
+    for (size_t g = 0; g < plan->replicas.size(); ++g) {
+        Plan& p = plan->replicas[g]->p;
+        DeviceGuard dev(p.device);
+        backend::sync_device();
+        word |= fused_check(p, nullptr, true, true);
+    }
     delete plan;
+    if (word)
+        return set_err(MI355FFT_ERR_HIP, "a fused two-pass launch of a replica of the destroyed multi-device plan gave up waiting for a dependency and nobody asked: the results of that call are INVALID");
     return MI355FFT_OK;
 }
 int mi355fft_multi_plan_shards(const mi355fft_multi_plan* plan) { return plan ? (int)plan->replicas.size() : 0; }

@@ -189,7 +189,8 @@ template <class T, class S, int F, bool FIRST, bool SPLIT, int ABL = 0> KernelEn
 // lower index has been claimed by a workgroup that is already running when an item starts to wait.  Without tickets the same
 // holds per XCD because a dispatcher walks its share of the grid in order (identical resource needs, nothing to reorder), and
 // then for the chip: the XCD with the lowest dispatch frontier cannot hold a waiter whose dependency lies beyond a frontier.
-template <class T> __device__ __forceinline__ void k2f_wait(unsigned* ctr, unsigned target, const K2FusedParams<T>& fp) {
+// returns true when the wait gave up
+template <class T> __device__ __forceinline__ bool k2f_wait(unsigned* ctr, unsigned target, const K2FusedParams<T>& fp) {
     int spins = 0;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(8);
@@ -197,9 +198,19 @@ template <class T> __device__ __forceinline__ void k2f_wait(unsigned* ctr, unsig
             // the word lives in pinned host memory and no launch clears it: a plain system-scope store (no PCIe atomic needed), visible to
             // the host at the latest when this launch completes
             __hip_atomic_store(fp.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            break;
+            return true;
         }
     }
+    return false;
+}
+// A tile whose wait gave up still runs (the launch must terminate and the counters must advance), but everything it stores is POISONED: the
+// sign it multiplies imaginary parts with on the way out becomes NaN.  A first-pass tile that overwrites a ring slot too early therefore
+// writes NaN, not plausible numbers, and every second-pass tile that reads a poisoned or half-written column produces NaN in all of that
+// column's outputs: the rows a give-up touched come back as NaN whatever the caller does next (src/lib.rs:184: never silently wrong).
+template <class T> __device__ __forceinline__ K2Params<T> k2f_poisoned(const K2Params<T>& p, bool gave_up) {
+    K2Params<T> q = p;
+    if (gave_up) q.sgn_out = __builtin_nanf("");
+    return q;
 }
 // RINGV: how the ring is accessed -- bit 0: the first pass stores it with agent-scope (write-through) stores, so no release fence;
 // bit 1: the second pass loads it with agent-scope (L1-bypassing) loads, so no acquire fence (cx.h st_agent / ld_agent)
@@ -209,6 +220,8 @@ __global__ __launch_bounds__((k2_threads<S0, F0, ABL0>()), (k2_threads<S0, F0, A
     static_assert(!(ABL0 & 4096), "the first pass runs on a plain executor (its ring stores are per element)");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ unsigned s_ticket;
+    __shared__ unsigned s_gave_up;
+    if (threadIdx.x == 0) s_gave_up = 0u;  // (published by the barrier every path below passes before the flag is read)
     long long w = (long long)blockIdx.x;
     if (fp.mode & 2) {
         if (threadIdx.x == 0) s_ticket = atomicAdd(fp.ctrl, 1u);
@@ -224,12 +237,14 @@ __global__ __launch_bounds__((k2_threads<S0, F0, ABL0>()), (k2_threads<S0, F0, A
     const bool sync = (fp.mode & 1) != 0;
     const bool release = sync && !(RINGV & 1) && !(fp.mode & 4), acquire = sync && !(RINGV & 2) && !(fp.mode & 8);  // mode bits 2, 3: probes
     if (it.pass == 0) {
+        bool gave_up = false;
         if (sync && it.use > 0) {
-            if (threadIdx.x == 0) k2f_wait(rd, it.use * (unsigned)fp.tiles[1], fp);
+            if (threadIdx.x == 0 && k2f_wait(rd, it.use * (unsigned)fp.tiles[1], fp)) s_gave_up = 1u;
             __syncthreads();
+            gave_up = __builtin_amdgcn_readfirstlane((int)s_gave_up) != 0;
         }
         DevExec<T, regs_needed<S0, SPLIT0>()> ex;
-        k2_tile<T, S0, F0, true, SPLIT0, ABL0, (RINGV & 1)>(ex, fp.pass[0], fp.pass[0].in + it.g * n, ring, it.tile, it.tile_out, smem);
+        k2_tile<T, S0, F0, true, SPLIT0, ABL0, (RINGV & 1)>(ex, k2f_poisoned(fp.pass[0], gave_up), fp.pass[0].in + it.g * n, ring, it.tile, it.tile_out, smem);
         if (sync) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -240,16 +255,18 @@ __global__ __launch_bounds__((k2_threads<S0, F0, ABL0>()), (k2_threads<S0, F0, A
             }
         }
     } else {
+        bool gave_up = false;
         if (sync) {
             if (threadIdx.x == 0) {
-                k2f_wait(written, (it.use + 1u) * (unsigned)fp.tiles[0], fp);
+                if (k2f_wait(written, (it.use + 1u) * (unsigned)fp.tiles[0], fp)) s_gave_up = 1u;
                 if (acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
+            gave_up = __builtin_amdgcn_readfirstlane((int)s_gave_up) != 0;
         }
         // (ABL bit 4096: the second pass as two columns per lane -- 16-byte ring loads and 16-byte stores, launch.h DevExecPair)
         typename std::conditional<(ABL1 & 4096) != 0, DevExecPair<T, regs_needed<S1, SPLIT1>()>, DevExec<T, regs_needed<S1, SPLIT1>()>>::type ex;
-        k2_tile<T, S1, F1, false, SPLIT1, ABL1, (RINGV & 2)>(ex, fp.pass[1], (const cx<T>*)ring, fp.pass[1].out + it.g * n, it.tile, it.tile_out, smem);
+        k2_tile<T, S1, F1, false, SPLIT1, ABL1, (RINGV & 2)>(ex, k2f_poisoned(fp.pass[1], gave_up), (const cx<T>*)ring, fp.pass[1].out + it.g * n, it.tile, it.tile_out, smem);
         if (sync) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();

@@ -20,6 +20,7 @@
 
 #include "backend.h"
 #include "kernels_params.h"
+#include "lsm_plan.h"
 
 namespace mi355 {
 
@@ -45,6 +46,9 @@ static int fail_alloc(const char* what, size_t bytes) {
                        why.c_str(), fr, tot, have ? "" : " (hipMemGetInfo failed too)");
 }
 
+constexpr int KIND_LSM = 22;  // lsm_launch.h
+void register_lsm_f32(std::vector<KernelEntry>&);
+void register_lsm_f64(std::vector<KernelEntry>&);
 static std::once_flag g_reg_once;
 std::vector<KernelEntry>& registry() {
     static std::vector<KernelEntry> r;
@@ -55,6 +59,8 @@ void ensure_registry() {
         auto& r = registry();
         register_k1_f32(r);
         register_k1_f64(r);
+        register_lsm_f32(r);
+        register_lsm_f64(r);
         register_k2_f32(r);
         register_k2_f64(r);
         register_k2f_f32(r);
@@ -925,6 +931,65 @@ template <class T> static int build_plan_t(Plan& plan) {
     const bool rader_ok = (algo == MI355FFT_ALGO_AUTO || algo == MI355FFT_ALGO_RADER);
     const bool bluestein_ok = (algo == MI355FFT_ALGO_AUTO || algo == MI355FFT_ALGO_BLUESTEIN);
     if (algo == MI355FFT_ALGO_RADER && (!is_prime_sz(n) || n < 5)) return MI355FFT_ERR_UNSUPPORTED;  // raders_algorithm.rs:68
+    // Lengths with prime factors outside the compiled radix set that fit one workgroup: the LDS stage machine (lsm.h) runs the tree
+    // the reference plans for them -- MixedRadix over the smooth part and one Rader per large prime factor, Rader over a recursively
+    // planned inner length (src/plan.rs:412-425, 474-506, 636-665) -- as ONE kernel from a run-time program.  A host planner's
+    // MixedRadix (composite) / Rader (prime) request gets it too.
+    // Returns 1 when the plan was made, 0 when this length is not taken, an error otherwise.  `always`: whatever the program costs.
+    auto try_lsm = [&](bool always) -> int {
+        if (algo == MI355FFT_ALGO_BLUESTEIN || n > 16384 || plan.opt_rader || env_int("MI355FFT_NO_LSM") != 0) return 0;  // (a host planner's finished Rader table is in the reference's form: the compiled / run-time Rader bodies take it)
+        lsm::Hooks hooks;
+        hooks.tw = [](size_t i, size_t len) {
+            double re, im;
+            twiddle_f64(i, len, &re, &im);
+            return cd(re, im);
+        };
+        hooks.dft = [](std::vector<cd>& v) { host_dft(v); };
+        lsm::Program best;
+        const KernelEntry* lk = nullptr;
+        for (auto& e : registry())
+            if (e.kind == KIND_LSM && e.prec == plan.prec) lk = &e;
+        const bool have = lk && lsm::build_program((int)n, (int)(2 * sizeof(T)), hooks, best);
+        // AUTO takes the program where it beat the Bluestein plan of the length in an on-device A/B over 400 random lengths per precision
+        // (profiles/r6/lsm_calib_*.jsonl, tools/r6_lsm_calib_report.py), by program length -- the one-kernel Bluestein it competes with up to
+        // 4096 runs 1.7 - 2.6 TB/s, the split-exchange and two-kernel forms above it 0.6 - 1.2:
+        //   Complex<f32>: <= 7 stages up to 4096 (median x1.13 .. x1.27), <= 11 up to 8192 (x1.2 .. x2.4), <= 16 above (x1.36 .. x1.65)
+        //   Complex<f64>: <= 5 stages up to 4096 (x1.09 .. x1.14), <= 8 up to 8192 (x1.03 .. x1.29)
+        const int calibrated = sizeof(T) == 4 ? (n <= 4096 ? 7 : n <= 8192 ? 11 : 16) : (n <= 4096 ? 5 : 8);
+        const int max_stages = env_int("MI355FFT_LSM_MAX_STAGES") ? env_int("MI355FFT_LSM_MAX_STAGES") : calibrated;
+        if (have && ((int)best.stages.size() <= max_stages || always)) {
+            if (lk->prepare()) return -MI355FFT_ERR_HIP;
+            plan.kind = PLAN_SINGLE;
+            PassDesc pd{};
+            pd.k = lk;
+            std::vector<T> lt = to_interleaved<T>(best.ltab), gt = to_interleaved<T>(best.gtab);
+            if (gt.empty()) gt.assign(2, (T)0);
+            std::vector<unsigned short> perms(best.ldperm);
+            perms.insert(perms.end(), best.stperm.begin(), best.stperm.end());
+            pd.lsm.d_stages = upload<LsmStage>(plan, best.stages, &rc);
+            if (rc) return -rc;
+            pd.lsm.d_desc = upload<unsigned>(plan, best.desc, &rc);
+            if (rc) return -rc;
+            pd.lsm.d_ltab = upload<T>(plan, lt, &rc);
+            if (rc) return -rc;
+            pd.lsm.d_gtab = upload<T>(plan, gt, &rc);
+            if (rc) return -rc;
+            pd.lsm.d_ldperm = upload<unsigned short>(plan, perms, &rc);
+            if (rc) return -rc;
+            pd.lsm.d_stperm = (unsigned short*)pd.lsm.d_ldperm + best.ldperm.size();
+            pd.lsm.nstages = (int)best.stages.size();
+            pd.lsm.ltab_n = (int)best.ltab.size();
+            pd.lsm.n = (int)n;
+            pd.lsm.f = best.f;
+            pd.lsm.tab_off = best.tab_off;
+            pd.lsm.nt = best.nt;
+            pd.lsm.lds_bytes = (int)(best.lds_elems * 2 * sizeof(T));
+            pd.lsm.desc = best.desc_str;
+            plan.passes.push_back(pd);
+            return 1;
+        }
+        return 0;
+    };
     std::vector<size_t> radices;
     if (direct_ok) {
         if (const KernelEntry* k = find_kernel(KIND_K1, plan.prec, n)) {
@@ -998,6 +1063,15 @@ template <class T> static int build_plan_t(Plan& plan) {
         // heights 37 .. 631 (k2r_body: Rader inside the tile) -- the reference's MixedRadix over Rader inner FFTs for lengths such
         // as 101 x 103 (src/plan.rs:474-506).  At or below 4096 (37 x 41: the one-kernel Bluestein moves each row once) only a host
         // planner's MixedRadix recipe takes the prime tiles.
+        // at or below 4096 the stage machine is the one-kernel form of the reference's MixedRadix over Rader: a host planner's MixedRadix request
+        // gets it whatever it costs, AUTO where its program is short (measured against the one-kernel Bluestein: profiles/r6/lsm_vs_bluestein_*.jsonl)
+        bool rader_body = false;  // (a compiled Rader body -- the primes <= 4096 with 31-smooth p - 1 -- is faster than the stage machine's Rader)
+        for (auto& e0 : registry()) rader_body = rader_body || (e0.kind == KIND_RADER && e0.prec == plan.prec && (size_t)e0.aux == n && e0.variant == 0);
+        if (n <= 4096 && !rader_body) {
+            const int r = try_lsm(algo == MI355FFT_ALGO_MIXED_RADIX);
+            if (r < 0) return -r;
+            if (r > 0) return MI355FFT_OK;
+        }
         bool general = n < ((size_t)1 << 31) && choose_general_radices(plan.prec, n, radices);
         if (general && n <= 4096) {
             bool prime_tile = false;
@@ -1084,6 +1158,11 @@ template <class T> static int build_plan_t(Plan& plan) {
             plan.passes.push_back(pd);
             return MI355FFT_OK;
         }
+    }
+    {  // everything that reaches this point would take Bluestein (or the run-time scheduled Rader below): the stage machine first
+        const int r = try_lsm(algo != MI355FFT_ALGO_AUTO);
+        if (r < 0) return -r;
+        if (r > 0) return MI355FFT_OK;
     }
     // primes whose p - 1 is 13-smooth and that have no compiled body: run-time scheduled Rader.  Measured slower than the
     // one-workgroup Bluestein on MI355X, so AUTO does not pick it; a host planner asks for it with MI355FFT_ALGO_RADER.
@@ -1351,6 +1430,8 @@ std::string Plan::describe() const {
     for (size_t i = 0; i < passes.size(); ++i) {
         if (i == 2 && fuse_on && fused) s << "}";  // three passes: the first two in one launch
         s << (i ? (fuse_on && fused && i == 1 ? " | " : " -> ") : "") << passes[i].k->name;
+        if (passes[i].k->kind == KIND_LSM)
+            s << "<" << passes[i].lsm.desc << ">x" << passes[i].lsm.nt << "t" << passes[i].lsm.nstages << "s" << "F" << passes[i].lsm.f;
         if (passes[i].k->kind == KIND_DYN_K1 || passes[i].k->kind == KIND_DYN_RADER) {
             const DynSched& d = passes[i].dyn;
             s << "<" << d.n << ", " << d.tpf;
@@ -1507,6 +1588,28 @@ static int launch_pass(const Plan& plan, size_t pi, const void* in, void* out, s
         p.batch = (long long)batch;
         p.sgn = inverse ? (T)-1 : (T)1;
         grid = (long long)((batch + k.f - 1) / k.f);
+        if (grid > kMaxGrid) return grid_too_large(pi, k, grid, batch);
+        k.launch(&p, grid, stream);
+    } else if (k.kind == KIND_LSM) {
+        LsmParams<T> p{};
+        p.in = (const cx<T>*)in;
+        p.out = (cx<T>*)out;
+        p.stages = (const LsmStage*)pd.lsm.d_stages;
+        p.desc = (const unsigned*)pd.lsm.d_desc;
+        p.ltab = (const cx<T>*)pd.lsm.d_ltab;
+        p.gtab = (const cx<T>*)pd.lsm.d_gtab;
+        p.ldperm = (const unsigned short*)pd.lsm.d_ldperm;
+        p.stperm = (const unsigned short*)pd.lsm.d_stperm;
+        p.batch = (long long)batch;
+        p.nstages = pd.lsm.nstages;
+        p.ltab_n = pd.lsm.ltab_n;
+        p.n = pd.lsm.n;
+        p.f = pd.lsm.f;
+        p.tab_off = pd.lsm.tab_off;
+        p.nt = pd.lsm.nt;
+        p.lds_bytes = pd.lsm.lds_bytes;
+        p.sgn = inverse ? (T)-1 : (T)1;
+        grid = (long long)((batch + pd.lsm.f - 1) / pd.lsm.f);
         if (grid > kMaxGrid) return grid_too_large(pi, k, grid, batch);
         k.launch(&p, grid, stream);
     } else if (k.kind == KIND_DYN_K1) {

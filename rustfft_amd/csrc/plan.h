@@ -8,6 +8,7 @@
 
 #include "../../include/mi355fft.h"
 #include "dyn_engine.h"
+#include "lsm.h"
 #include "backend.h"
 #include "registry.h"
 
@@ -44,6 +45,12 @@ struct PassDesc {
     void* d_perm_in;   // Rader: g^(j+1) mod p
     void* d_perm_out;  // Rader: g^-(j+1) mod p
     DynSched dyn;      // run-time schedule (KIND_DYN_K1 / KIND_DYN_RADER)
+    // LDS stage machine (KIND_LSM, lsm.h): the program's device tables and launch geometry
+    struct Lsm {
+        void *d_stages = nullptr, *d_desc = nullptr, *d_ltab = nullptr, *d_gtab = nullptr, *d_ldperm = nullptr, *d_stperm = nullptr;
+        int nstages = 0, ltab_n = 0, n = 0, f = 1, tab_off = 0, nt = 256, lds_bytes = 0;
+        std::string desc;
+    } lsm;
     long long row_n;   // transform length this pass belongs to when it is not the plan's own (fused Bluestein: M); 0 = plan.len
 };
 

@@ -264,6 +264,11 @@ class Fft:
         self._check(self._lib.mi355fft_plan_fused_status(self._h, self._stream(), ctypes.byref(w)))
         return int(w.value)
 
+    def synchronize(self):
+        """Waits for torch's current stream and raises if a fused launch of this plan on it gave up a dependency wait: the verdict an asynchronous
+        device call cannot return itself (mi355fft_plan_synchronize; src/lib.rs:184)."""
+        self._check(self._lib.mi355fft_plan_synchronize(self._h, self._stream()))
+
     def workspace_bytes(self):
         """HBM the plan currently holds as per-stream workspaces."""
         return int(self._lib.mi355fft_plan_workspace_bytes(self._h))

@@ -121,6 +121,7 @@ pub mod ffi {
         pub fn mi355fft_plan_set_fused(plan: *mut Mi355Plan, mode: c_int) -> c_int;
         pub fn mi355fft_plan_is_fused(plan: *const Mi355Plan) -> c_int;
         pub fn mi355fft_plan_fused_status(plan: *const Mi355Plan, stream: *mut c_void, error_word: *mut c_uint) -> c_int;
+        pub fn mi355fft_plan_synchronize(plan: *const Mi355Plan, stream: *mut c_void) -> c_int;
         pub fn mi355fft_plan_set_fused_wait_limit(plan: *mut Mi355Plan, polls: c_int) -> c_int;
         pub fn mi355fft_plan_set_workspace_placement(plan: *mut Mi355Plan, on: c_int) -> c_int;
         pub fn mi355fft_plan_set_chunk_batch(plan: *mut Mi355Plan, chunk_batch: usize) -> c_int;
@@ -269,6 +270,15 @@ mod hip {
         /// asynchronous on `stream` (a `hipStream_t`; null = the default stream).
         pub unsafe fn process_device(&self, buffer: *mut c_void, batch: usize, stream: *mut c_void) {
             let rc = ffi::mi355fft_process_inplace_dev(self.plan, buffer, batch, stream);
+            if rc != 0 {
+                hip_panic(rc)
+            }
+        }
+        /// Waits for everything enqueued on `stream` and panics if a fused launch of this plan gave up a dependency wait -- the one
+        /// failure the asynchronous `process_*_device` calls cannot report themselves (src/lib.rs:184: never silently wrong).  Call it
+        /// before reading results produced by the device entry points.
+        pub unsafe fn synchronize(&self, stream: *mut c_void) {
+            let rc = ffi::mi355fft_plan_synchronize(self.plan, stream);
             if rc != 0 {
                 hip_panic(rc)
             }

@@ -1329,6 +1329,57 @@ def test_fused_giveup_cannot_be_missed_on_the_device(planners, dtype, log2n, bat
     assert fft.fused_status() == 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,log2n,batch", [(np.complex64, 16, 512), (np.complex64, 20, 96), (np.complex128, 19, 64)])
+def test_fused_giveup_is_visible_without_a_second_call(dtype, log2n, batch):
+    """Round 6 (the review's asynchronous hole): `process_dev` -> the caller synchronises the stream ITSELF -> reads the result -> never calls
+    the plan again.  The verdict must still be there: (a) the data says so -- every row a give-up touched carries NaN, and every row WITHOUT
+    NaN is the right answer; (b) `synchronize()` (mi355fft_plan_synchronize) raises, once.  Real give-ups through a wait limit of 0."""
+    import torch
+
+    import rustfft_amd
+
+    n = 1 << log2n
+    tdt = torch.complex64 if dtype == np.complex64 else torch.complex128
+    fft = rustfft_amd.FftPlanner(dtype).plan_fft_forward(n)
+    assert fft.is_fused()
+    x = torch.empty(batch * n, dtype=tdt, device="cuda")
+    torch.view_as_real(x).uniform_(-1.0, 1.0)
+    want = x.clone()
+    fft.process(want)
+    fft.synchronize()  # healthy launch: no error
+    stream = torch.cuda.current_stream()
+    fft.set_fused_wait_limit(0)
+    seen = 0
+    for it in range(16):
+        y = x.clone()
+        fft.process(y)  # enqueues fine whatever happens on the device
+        stream.synchronize()  # the caller's own synchronisation: nothing of the library is asked
+        rows = torch.view_as_real(y).reshape(batch, -1)
+        bad = torch.isnan(rows).any(dim=1)
+        good = ~bad
+        # (a) rows without NaN are right, bit for bit (the fused launch is bit-repeatable)
+        assert torch.equal(rows[good], torch.view_as_real(want).reshape(batch, -1)[good]), (it, int(bad.sum()))
+        # (b) the reporting synchronize: raises exactly when a wait gave up, and only once
+        try:
+            fft.synchronize()
+            gave_up = False
+        except rustfft_amd.FftPanic as e:
+            gave_up = True
+            assert e.status == 8 and "gave up waiting for a dependency" in str(e), str(e)
+        assert gave_up == bool(bad.any()) or gave_up, "NaN rows without a reported give-up"
+        if gave_up:
+            seen += 1
+            assert bool(bad.any()), "a wait gave up but no row carries NaN: the tile's output could be mistaken for data"
+        fft.synchronize()  # reported once
+    assert seen >= 1 or log2n < 19, "a wait limit of 0 produced no give-up in 16 launches"  # (2^16 meets its dependencies at the first poll almost always)
+    fft.set_fused_wait_limit(1 << 21)
+    y = x.clone()
+    fft.process(y)
+    fft.synchronize()
+    assert torch.equal(torch.view_as_real(y), torch.view_as_real(want))
+
+
 _HOG = r"""
 import random, sys, time, torch
 a = torch.empty(1 << 28, dtype=torch.float32, device="cuda"); b = torch.empty_like(a)   # 1 GiB each: HBM traffic

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--check", action="store_true", help="also compare the two builds' results on four rows (relative L2 of b against a)")
     ap.add_argument("--no-trim", action="store_true", help="keep every plan's workspace (what this tool did before round 4's last hour: a sweep over hundreds of multi-pass lengths then runs the device out of memory)")
     ap.add_argument("--a-algo", default="", choices=["", "bluestein"], help="plan side a through the host-planner entry point with this algorithm (same library on both sides: AUTO's choice against Bluestein)")
+    ap.add_argument("--b-algo", default="", choices=["", "tree"], help="plan side b through the host-planner entry point as the reference's tree: Rader for a prime, MixedRadix otherwise (round 6: the LDS stage machine whatever its program costs)")
     ap.add_argument("--all", action="store_true", help="time a length even when both builds describe the same plan (a changed kernel body keeps its name)")
     args = ap.parse_args()
     dt, tdt, esz = (np.complex64, torch.complex64, 8) if args.dtype == "f32" else (np.complex128, torch.complex128, 16)
@@ -60,6 +61,12 @@ def main():
         ffts = [p.plan_fft_forward(n) for p in pl]
         if args.a_algo == "bluestein":
             ffts[0] = pl[0].plan_fft_with(n, 0, algorithm=rustfft_amd.ALGO_BLUESTEIN)
+        if args.b_algo == "tree":
+            prime = n > 3 and all(n % q for q in range(2, int(n**0.5) + 1))
+            try:
+                ffts[1] = pl[1].plan_fft_with(n, 0, algorithm=rustfft_amd.ALGO_RADER if prime else rustfft_amd.ALGO_MIXED_RADIX)
+            except Exception:
+                continue  # no tree within the machine's limits
         if ffts[0].describe() == ffts[1].describe() and not args.all:
             continue
         diff = None
