@@ -170,9 +170,17 @@ def side_line(torch, np, log, steps=3):
             acc += float((v[i:i + chunk].double() ** 2).sum().item())
         return acc
 
-    res = {}
+    # schema 2 (round 5 on): ms_per_step / frac_of_8TBps of a side config are the IN-PLACE figures (Fft::process), the x -> y figures of rounds
+    # 3 - 4 live under "immutable_input" -- same-named keys of BENCH_r03 / r04 are 5 - 10 % lower for that reason alone
+    res = {"schema": 2}
     for key, n, batch, dt, tdt, esz, name in (("c3", 1200, 65536, np.complex128, torch.complex128, 16, "f64"),
                                              ("c4", 1009, 1 << 20, np.complex64, torch.complex64, 8, "f32"),
+                                             # BASELINE.md's C4 row names 1019 as the complementary prime (1018 = 2 x 509: the reference plans it as Bluestein over
+                                             # M = 2048, src/plan.rs:636-665; so does this library): the weakest BASELINE-named workload rides in the driver's line
+                                             ("c4_bluestein", 1019, 1 << 20, np.complex64, torch.complex64, 8, "f32"),
+                                             # round 6: a length with a large prime factor through the LDS stage machine (64 x 37: the reference's
+                                             # MixedRadix over Rader, one kernel from a run-time program) -- the family that left whole-length Bluestein
+                                             ("tree_2368", 2368, 1 << 19, np.complex64, torch.complex64, 8, "f32"),
                                              ("c5_shard", 1 << 22, 1024, np.complex64, torch.complex64, 8, "f32")):
         try:
             fft = rustfft_amd.FftPlanner(dt).plan_fft_forward(n)

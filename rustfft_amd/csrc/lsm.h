@@ -52,6 +52,7 @@ struct LsmStage {
     int pdesc_off;  // first pre-multiplier index of the stage (stages with LSM_PRE_MUL)
     float cfix;     // FIX / BFLY2: S[0] += cfix * x[0]   (= -(q - 1): 1 / D[0], lsm_plan.h)
     int fix_off;    // BFLY2: slot of x[0] relative to the base of the item that holds S[0] (bit 31 of its pre-multiplier word marks that item)
+    int round;      // work items the workgroup takes per ROUND: NT x the items a thread holds at this radix; a stage with more runs several rounds
 };
 
 template <class T> struct LsmParams {
@@ -75,11 +76,11 @@ template <class T> struct LsmParams {
 // Register budget (the kernel should hold four waves per SIMD, i.e. 128 VGPRs): the data (2 EMAX), the twiddles of every item (fetched
 // with the data: < 2 EMAX) and one word per item.
 template <int R, int NT, class T>
-MI_HD void lsm_bfly(const LsmStage& st, const LsmParams<T>& p, int tid, cx<T>* lds, const cx<T>* ltab, const unsigned* dw, const unsigned* dp) {
+MI_HD void lsm_bfly(const LsmStage& st, const LsmParams<T>& p, int tid, cx<T>* lds, const cx<T>* ltab, const unsigned* dw, const unsigned* dp, int left) {
     constexpr int IMAX = (kLsmEmax / R) < kLsmItems ? (kLsmEmax / R) : kLsmItems;
     static_assert(IMAX >= 1, "radix exceeds the register budget");
     cx<T> v[IMAX * R];  // the data of the thread's items: live within the stage only (nothing but the descriptor words crosses a barrier in registers)
-    const int total = st.total, flags = st.flags;
+    const int total = left, flags = st.flags;  // (items of this round and beyond: the guards below stop at the thread's IMAX)
     const bool has_tw = (flags & (LSM_TW_PRE | LSM_TW_POST)) != 0;
     // Factors: radices up to 8 fetch them WITH the data (one LDS round trip per stage); the larger ones -- one item per thread, 2 R data
     // registers and a butterfly that needs as many temporaries -- fetch them right where they are used, so that they are not live across
@@ -162,9 +163,9 @@ MI_HD void lsm_bfly(const LsmStage& st, const LsmParams<T>& p, int tid, cx<T>* l
 // twiddle multiplies use ONE set of factors: the decimation-in-time last stage and the decimation-in-frequency first stage of a length share
 // stride and radix, hence the table.
 template <int R, int NT, class T>
-MI_HD void lsm_bfly2(const LsmStage& st, const LsmParams<T>& p, int tid, cx<T>* lds, const cx<T>* ltab, const unsigned* dw, const unsigned* dp) {
+MI_HD void lsm_bfly2(const LsmStage& st, const LsmParams<T>& p, int tid, cx<T>* lds, const cx<T>* ltab, const unsigned* dw, const unsigned* dp, int left) {
     constexpr int IMAX = (kLsmEmax / R) < kLsmItems ? (kLsmEmax / R) : kLsmItems;
-    const int total = st.total, flags = st.flags;
+    const int total = left, flags = st.flags;
     const bool has_tw = (flags & (LSM_TW_PRE | LSM_TW_POST)) != 0;
     constexpr bool AHEAD = R <= 8;
     cx<T> v[IMAX * R], tw[IMAX * R];
@@ -224,10 +225,10 @@ MI_HD void lsm_bfly2(const LsmStage& st, const LsmParams<T>& p, int tid, cx<T>* 
     });
 }
 // LSM_X0MUL: a Rader node that FOLLOWS a six-step twiddle takes the factor of its x[0] here (the fused stage has one table index per item)
-template <int NT, class T> MI_HD void lsm_x0mul(const LsmStage& st, const LsmParams<T>& p, int tid, cx<T>* lds, const cx<T>* ltab, const unsigned* dw, const unsigned* dp) {
+template <int NT, class T> MI_HD void lsm_x0mul(const LsmStage& st, const LsmParams<T>& p, int tid, cx<T>* lds, const cx<T>* ltab, const unsigned* dw, const unsigned* dp, int left) {
     static_for<0, kLsmItems>([&](auto J_) {
         constexpr int j = J_;
-        if (j * NT < st.total && tid + j * NT < st.total) {
+        if (j * NT < left && tid + j * NT < left) {
             const int px = (int)(dw[j] & 0xffffu);
             lds[px] = lds[px] * ((st.flags & LSM_PRE_GLOBAL) ? p.gtab[dp[j]] : ltab[dp[j]]);
         }
@@ -239,10 +240,10 @@ template <int NT, class T> MI_HD void lsm_x0mul(const LsmStage& st, const LsmPar
 //     X[0] = x[0] + S[0];      S[0] += x[0] / D[0]
 // so that the spectrum multiply that follows turns bin 0 into S[0] D[0] + x[0], which the second inner transform spreads
 // as "+ x[0]" over every output (raders_algorithm.rs:256-266 does the same with conj(x[0]) between its two conjugations).
-template <int NT, class T> MI_HD void lsm_fix(const LsmStage& st, const LsmParams<T>& p, int tid, cx<T>* lds, const cx<T>* ltab, const unsigned* dw, const unsigned* dp) {
+template <int NT, class T> MI_HD void lsm_fix(const LsmStage& st, const LsmParams<T>& p, int tid, cx<T>* lds, const cx<T>* ltab, const unsigned* dw, const unsigned* dp, int left) {
     static_for<0, kLsmItems>([&](auto J_) {
         constexpr int j = J_;
-        if (j * NT < st.total && tid + j * NT < st.total) {
+        if (j * NT < left && tid + j * NT < left) {
             const int ps = (int)(dw[j] & 0xffffu), px = ps + st.astep;
             cx<T> s0 = lds[ps], x0 = lds[px];
             if (st.flags & LSM_PRE_MUL) x0 = x0 * ((st.flags & LSM_PRE_GLOBAL) ? p.gtab[dp[j]] : ltab[dp[j]]);
@@ -275,11 +276,11 @@ template <int NT, class T> MI_HD void lsm_fix(const LsmStage& st, const LsmParam
 // descriptor words of a stage for this thread: item j of the thread is item tid + j NT of the workgroup.  Only the words the stage has
 // are requested (the guards are workgroup-uniform): a fetch is a global load plus its address arithmetic, and most stages have one or two
 // items per thread and no pre-multiplier
-template <int NT> MI_HD void lsm_fetch_desc(const LsmStage& st, const unsigned* MI_RESTRICT desc, int tid, unsigned* dw, unsigned* dp) {
+template <int NT> MI_HD void lsm_fetch_desc(const LsmStage& st, const unsigned* MI_RESTRICT desc, int tid, unsigned* dw, unsigned* dp, int r0 = 0) {
     static_for<0, kLsmItems>([&](auto J_) {
         constexpr int j = J_;
-        if (j * NT < st.total) {
-            const int item = tid + j * NT, ic = item < st.total ? item : 0;
+        if (j * NT < st.round && r0 + j * NT < st.total) {
+            const int item = r0 + tid + j * NT, ic = item < st.total ? item : 0;
             dw[j] = desc[(unsigned)(st.desc_off + ic)];
             if (st.flags & LSM_PRE_MUL) dp[j] = desc[(unsigned)(st.pdesc_off + ic)];
         }
@@ -359,14 +360,20 @@ template <class T, int NT, class X> MI_HD void lsm_body(X& ex, const LsmParams<T
             unsigned* nxt = cur + 2 * kLsmItems;
             // the NEXT stage's words are requested now and consumed behind the next barrier: their latency hides behind this stage
             if (s + 1 < p.nstages) lsm_fetch_desc<NT>(stn, p.desc, tid, nxt, nxt + kLsmItems);
-            if (st.op == LSM_FIX) {
-                lsm_fix<NT, T>(st, p, tid, lds, ltab, cur, cur + kLsmItems);
-            } else if (st.op == LSM_X0MUL) {
-                lsm_x0mul<NT, T>(st, p, tid, lds, ltab, cur, cur + kLsmItems);
-            } else if (st.op == LSM_BFLY2) {
-                MI_LSM_RADIX_SWITCH(st.radix, (lsm_bfly2<RR, NT, T>(st, p, tid, lds, ltab, cur, cur + kLsmItems)));
-            } else {
-                MI_LSM_RADIX_SWITCH(st.radix, (lsm_bfly<RR, NT, T>(st, p, tid, lds, ltab, cur, cur + kLsmItems)));
+            // a stage with more work items than the workgroup holds at once runs in ROUNDS (in-place items are independent: no barrier in
+            // between); the first round's words were fetched a stage ahead, the later ones are fetched when their round starts
+            for (int r0 = 0; r0 < st.total; r0 += st.round) {
+                if (r0 > 0) lsm_fetch_desc<NT>(st, p.desc, tid, cur, cur + kLsmItems, r0);
+                const int left = (st.total - r0) < st.round ? (st.total - r0) : st.round;
+                if (st.op == LSM_FIX) {
+                    lsm_fix<NT, T>(st, p, tid, lds, ltab, cur, cur + kLsmItems, left);
+                } else if (st.op == LSM_X0MUL) {
+                    lsm_x0mul<NT, T>(st, p, tid, lds, ltab, cur, cur + kLsmItems, left);
+                } else if (st.op == LSM_BFLY2) {
+                    MI_LSM_RADIX_SWITCH(st.radix, (lsm_bfly2<RR, NT, T>(st, p, tid, lds, ltab, cur, cur + kLsmItems, left)));
+                } else {
+                    MI_LSM_RADIX_SWITCH(st.radix, (lsm_bfly<RR, NT, T>(st, p, tid, lds, ltab, cur, cur + kLsmItems, left)));
+                }
             }
             static_for<0, 2 * kLsmItems>([&](auto I_) { cur[decltype(I_)::value] = nxt[decltype(I_)::value]; });
         });

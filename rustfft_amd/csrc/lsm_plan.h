@@ -19,6 +19,7 @@
 //                              stages read as TRN: x[g^(j-1)] in, X[g^(j+1)] out -- D does not depend on the offset a.
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <complex>
 #include <functional>
 #include <map>
@@ -69,6 +70,7 @@ struct Program {
     std::vector<cd> ltab, gtab;
     std::vector<unsigned short> ldperm, stperm;
     std::string desc_str;
+    int root_kind = LEAF;
     bool order_items = true;  // lane order of the work items by LDS bank (measurement builds switch it off)
     double est = 0;  // the cost model's SIMD time per row (arbitrary units): picks rows per workgroup and the block size
 };
@@ -120,7 +122,7 @@ inline int items_per_thread(int r) { return std::min(kLsmEmax / r, kLsmItems); }
 struct Ctx {
     int pmax = 13, nt = 256, emax = 16, row = 0;  // pmax: the largest prime radix of the kernel variant
     // a radix-r stage over the whole row fits the registers of one workgroup row: ceil((row / r) / nt) <= items a thread may hold
-    bool fits(int r) const { return (row / r + nt - 1) / nt <= items_per_thread(r); }
+    bool fits(int) const { return true; }  // (a stage with more items than the workgroup holds at once runs in rounds: lsm.h)
 };
 // rough VALU cost of one radix-r butterfly with its twiddles and slot arithmetic (instructions per work item; planning only)
 inline double item_cost(int r) {
@@ -557,6 +559,7 @@ inline bool finish(Program& prog, int esz) {
         st.p_kstep = h.p_kstep;
         st.cfix = h.cfix;
         st.fix_off = h.fix_off;
+        st.round = prog.nt * ((h.op == LSM_BFLY || h.op == LSM_BFLY2) ? items_per_thread(h.radix) : kLsmItems);
         std::vector<unsigned> dw, pd;
         for (int f = 0; f < F; ++f)
             for (int i = 0; i < h.items; ++i) {
@@ -587,7 +590,7 @@ inline bool finish(Program& prog, int esz) {
     return true;
 }
 
-inline bool build_program_nt(int n, int esz, int NT, const Hooks& hooks, Program& prog, size_t lds_budget, size_t lds_max) {
+inline bool build_program_nt(int n, int esz, int NT, const Hooks& hooks, Program& prog, size_t lds_budget, size_t lds_max, int force_f = 0) {
     prog = Program{};
 #if defined(MI355_LSM_PLAIN_ORDER)
     prog.order_items = false;
@@ -603,59 +606,79 @@ inline bool build_program_nt(int n, int esz, int NT, const Hooks& hooks, Program
     prog.n = n;
     prog.nt = NT;
     prog.rp = root->phys | 1;  // odd row pitch: lanes that walk across the rows of a workgroup fall on different banks
+    // Two placements of the six-step tables: with the other stage tables in LDS (one fetch latency less per use) or in global memory (a
+    // smaller workgroup: more rows or more workgroups per CU); the cost model picks.
     bool done = false;
-    for (int pass = 0; pass < 2 && !done; ++pass) {
+    Program bestp;
+    for (int pass = 0; pass < 2; ++pass) {
         prog.hstages.clear();
         prog.ltab.clear();
         prog.gtab.clear();
         Emitter em;
         em.prog = &prog;
         em.hooks = &hooks;
-        em.tw_global = pass == 1;  // second try: the six-step tables stay in global memory
+        em.tw_global = pass == 1;
 #if defined(MI355_LSM_NO_FUSE)
         em.fuse = false;
 #endif
         em.emit(*root, FWD, Frame{}, PreOp{});
         if (em.failed || prog.hstages.empty() || (int)prog.hstages.size() > kLsmMaxStages) return false;
-        // rows per workgroup: registers (every stage: ceil(F items / NT) <= items a thread may hold; LOAD / STORE: F n <= NT EMAX), then LDS
-        int freg = (NT * kLsmIoMax) / n;
-        for (auto& st : prog.hstages) {
-            const int ipt = (st.op == LSM_BFLY || st.op == LSM_BFLY2) ? items_per_thread(st.radix) : kLsmItems;
-            if (ipt < 1) return false;
-            freg = std::min(freg, (NT * ipt) / st.items);
-        }
-        freg = std::min(freg, 65535 / prog.rp);
-        if (freg < 1) return false;
+        if (pass == 1 && em.n_mixed == 0) break;  // nothing to move
+        // rows per workgroup: LOAD / STORE move at most kLsmIoMax elements per thread; 16-bit slots; LDS
+        int fmax = std::min((NT * kLsmIoMax) / n, 65535 / prog.rp);
+        if (fmax < 1) return false;
         const size_t tab = prog.ltab.size();
-        if (tab > 60000) return false;  // a twiddle row is a 16-bit field of the descriptor word
+        if (tab > 60000) continue;  // a twiddle row is a 16-bit field of the descriptor word
         auto lds_for = [&](int f) { return ((size_t)f * prog.rp + tab) * (size_t)esz; };
-        int fmax = freg;
         while (fmax > 1 && lds_for(fmax) > lds_budget) --fmax;
-        if (pass == 0 && em.n_mixed > 0 && (fmax < freg || lds_for(fmax) > lds_budget)) continue;
-        if (lds_for(fmax) > lds_max) return false;
+        if (lds_for(fmax) > lds_max) continue;
         // rows per workgroup by a cost model: SIMD time per row = sum over stages of (rounds x item cost + a fixed barrier / latency term) x
         // waves, over F rows -- a stage with F items = 1.1 NT pays two rounds for the work of one, a small F pays the barriers alone
         int F = fmax;
         double best_t = 1e30;
+        std::vector<double> cost_of(fmax + 1, 0.0);
         for (int f = 1; f <= fmax; ++f) {
             double t = 0;
             for (auto& st : prog.hstages) {
                 const int rounds = (f * st.items + NT - 1) / NT;
+                const int ipt = (st.op == LSM_BFLY || st.op == LSM_BFLY2) ? items_per_thread(st.radix) : kLsmItems;
+                if (rounds > ipt) t += 150.0 * ((rounds + ipt - 1) / ipt - 1);  // later rounds fetch their descriptor words in line
+                if (st.flags & LSM_PRE_GLOBAL) t += 60.0;                       // a table in global memory: its latency is not hidden by the stage
                 t += rounds * (st.op == LSM_BFLY ? item_cost(st.radix) : st.op == LSM_BFLY2 ? 1.8 * item_cost(st.radix) : 20.0) + 40.0 + 10.0 * (NT / 64.0);  // (a barrier costs more the more waves meet at it)
             }
             t += 2.0 * (((double)f * n + NT - 1) / NT) * 8.0 + 200.0;  // LOAD / STORE
-            t = t * (NT / 64.0) / f * (NT >= 1024 ? 1.3 : NT >= 512 ? 1.05 : 1.0);  // (the 1024-thread kernel lives in 128 VGPRs: it spills)
-            if (t < best_t * 0.97 || (t < best_t && f > F)) {
-                best_t = std::min(best_t, t);
+            t = t * (NT / 64.0) / f;
+            // resident waves hide the stages' LDS round trips and barriers: what the workgroup's LDS lets a CU hold (160 KiB; at most 16 waves
+            // at 128 VGPRs), counted against the dozen that keeps the SIMDs busy
+            const double wgs = std::max(1.0, std::min(32.0, std::floor(160.0 * 1024 / (double)lds_for(f))));
+            const double waves = std::min(16.0, wgs * (NT / 64.0));
+            t *= 12.0 / std::min(12.0, waves);
+            if (force_f > 0 && f == std::min(force_f, fmax)) {
+                best_t = t;
                 F = f;
             }
+            if (force_f == 0) cost_of[f] = t;
         }
-        prog.est = best_t;
-        prog.f = F;
-        prog.tab_off = F * prog.rp;
-        prog.lds_elems = (size_t)F * prog.rp + tab;
-        done = true;
+        if (force_f == 0) {
+            // Rows per workgroup from the MEASURED optimum (profiles/r6/lsm_ntf_sweep_f32.jsonl: 16 lengths x every block size x up to ten row
+            // counts): the rate peaks where a thread holds 13 .. 24 elements of the workgroup's rows per stage -- enough work between two
+            // barriers to hide them, within the four items a thread may hold -- and is flat to 3 % across block sizes at that load, so: the
+            // row count that brings the workgroup closest to 16 elements per thread; the cost above only ranks the block sizes
+            const double want = 16.0;
+            F = std::max(1, std::min(fmax, (int)std::lround(want * NT / n)));
+            const double e = (double)F * n / NT;
+            best_t = cost_of[F] * (e < 12.0 ? 1.0 + 0.12 * (12.0 - e) : e > 26.0 ? 1.0 + 0.04 * (e - 26.0) : 1.0) * (1.0 + 0.0002 * NT);
+        }
+        if (!done || best_t < bestp.est) {
+            prog.est = best_t;
+            prog.f = F;
+            prog.tab_off = F * prog.rp;
+            prog.lds_elems = (size_t)F * prog.rp + tab;
+            bestp = prog;
+            done = true;
+        }
     }
+    if (done) prog = bestp;
     if (!done || !finish(prog, esz)) return false;
     prog.ldperm.resize((size_t)prog.f * n);
     prog.stperm.resize((size_t)prog.f * n);
@@ -665,15 +688,18 @@ inline bool build_program_nt(int n, int esz, int NT, const Hooks& hooks, Program
             prog.stperm[(size_t)f * n + i] = (unsigned short)(f * prog.rp + root->out_pos[i]);
         }
     prog.desc_str = describe(*root);
+    prog.root_kind = root->kind;
     return true;
 }
 // Builds the program for length n (elements of `esz` bytes): workgroups of 64 .. 1024 threads, the one the cost model likes best.  Returns false when the length has no tree within the machine's limits (registers, LDS, 16-bit slots).
-inline bool build_program(int n, int esz, const Hooks& hooks, Program& prog, size_t lds_budget = 64 * 1024, size_t lds_max = 160 * 1024) {
+// (force_nt / force_f: measurement builds pin the block size and the rows per workgroup)
+inline bool build_program(int n, int esz, const Hooks& hooks, Program& prog, size_t lds_budget = 64 * 1024, size_t lds_max = 160 * 1024, int force_nt = 0, int force_f = 0) {
     bool have = false;
     for (int nt : {64, 128, 256, 512, 1024}) {
+        if (force_nt > 0 && nt != force_nt) continue;
         if (nt == 1024 && esz > 8) break;  // Complex<f64>: the 1024-thread kernel would have to live in 128 VGPRs (it spills)
         Program cand;
-        if (!build_program_nt(n, esz, nt, hooks, cand, lds_budget, lds_max)) continue;
+        if (!build_program_nt(n, esz, nt, hooks, cand, lds_budget, lds_max, force_f)) continue;
         if (!have || cand.est < prog.est) prog = std::move(cand);
         have = true;
     }

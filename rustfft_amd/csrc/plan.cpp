@@ -949,13 +949,18 @@ template <class T> static int build_plan_t(Plan& plan) {
         const KernelEntry* lk = nullptr;
         for (auto& e : registry())
             if (e.kind == KIND_LSM && e.prec == plan.prec) lk = &e;
-        const bool have = lk && lsm::build_program((int)n, (int)(2 * sizeof(T)), hooks, best);
+        bool have = lk && lsm::build_program((int)n, (int)(2 * sizeof(T)), hooks, best, 64 * 1024, 160 * 1024, env_int("MI355FFT_LSM_NT"), env_int("MI355FFT_LSM_F"));
+        // a host planner that names a family gets that family: Rader = a tree whose ROOT is Rader's algorithm (a prime above the radix set),
+        // MixedRadix = a composite (a prime is no MixedRadix: src/plan.rs:412-425)
+        if (have && algo == MI355FFT_ALGO_RADER && best.root_kind != lsm::RADER) have = false;
+        if (have && algo == MI355FFT_ALGO_MIXED_RADIX && best.root_kind == lsm::RADER) have = false;
         // AUTO takes the program where it beat the Bluestein plan of the length in an on-device A/B over 400 random lengths per precision
         // (profiles/r6/lsm_calib_*.jsonl, tools/r6_lsm_calib_report.py), by program length -- the one-kernel Bluestein it competes with up to
-        // 4096 runs 1.7 - 2.6 TB/s, the split-exchange and two-kernel forms above it 0.6 - 1.2:
-        //   Complex<f32>: <= 7 stages up to 4096 (median x1.13 .. x1.27), <= 11 up to 8192 (x1.2 .. x2.4), <= 16 above (x1.36 .. x1.65)
-        //   Complex<f64>: <= 5 stages up to 4096 (x1.09 .. x1.14), <= 8 up to 8192 (x1.03 .. x1.29)
-        const int calibrated = sizeof(T) == 4 ? (n <= 4096 ? 7 : n <= 8192 ? 11 : 16) : (n <= 4096 ? 5 : 8);
+        // 4096 runs 1.7 - 2.6 TB/s, the split-exchange and two-kernel forms above it 0.5 - 1.2:
+        //   Complex<f32>: <= 7 stages up to 4096 (medians x1.21, x1.31, x1.08, x1.04 at 4 .. 7 stages; 8: x0.89), <= 11 up to 8192 (x1.2 .. x2.1),
+        //                 <= 14 above (x1.07 .. x3.0; 15: x0.95)
+        //   Complex<f64>: <= 6 stages up to 4096 (x1.09, x1.25, x1.07; 7: x1.01 with 5 wins of 12), <= 8 up to 8192 (x1.05 .. x1.08), <= 14 above (x1.4 .. x2.0)
+        const int calibrated = sizeof(T) == 4 ? (n <= 4096 ? 7 : n <= 8192 ? 11 : 14) : (n <= 4096 ? 6 : n <= 8192 ? 8 : 14);
         const int max_stages = env_int("MI355FFT_LSM_MAX_STAGES") ? env_int("MI355FFT_LSM_MAX_STAGES") : calibrated;
         if (have && ((int)best.stages.size() <= max_stages || always)) {
             if (lk->prepare()) return -MI355FFT_ERR_HIP;

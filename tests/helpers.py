@@ -146,8 +146,15 @@ def check_host_planner_options(planner, oracle):
     assert "k1<" in planner.plan_fft_with(1024, 0, algorithm=rustfft_amd.ALGO_MIXED_RADIX).describe()
     with pytest.raises(rustfft_amd.FftPanic, match="no GPU plan"):
         planner.plan_fft_with(1019, 0, algorithm=rustfft_amd.ALGO_MIXED_RADIX)  # prime, 1018 = 2 * 509: nothing direct
-    with pytest.raises(rustfft_amd.FftPanic, match="no GPU plan"):
-        planner.plan_fft_with(1019, 0, algorithm=rustfft_amd.ALGO_RADER)  # 509 is not 13-smooth
+    # 1018 = 2 x 509, 508 = 4 x 127: until round 5 "no GPU plan"; round 6: Rader over MixedRadix over Rader ... as the reference recurses
+    # (src/plan.rs:636-665), one kernel from a run-time program (the LDS stage machine)
+    fr = planner.plan_fft_with(1019, 0, algorithm=rustfft_amd.ALGO_RADER)
+    assert fr.describe().startswith("lsm<rader1019[mixed{rader509["), fr.describe()
+    xr = random_signal(3 * 1019, dtype)
+    ar, br = xr.copy(), xr.copy()
+    fr.process(ar)
+    oracle.plan(dtype, 1019, 0).process(br)
+    assert compare_vectors(ar, br)
     x = random_signal(3 * 1024, dtype)
     a, b = x.copy(), x.copy()
     planner.plan_fft_with(1024, 0, algorithm=rustfft_amd.ALGO_BLUESTEIN).process(a)

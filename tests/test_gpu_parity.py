@@ -661,6 +661,94 @@ def test_rader_bodies_of_the_31_smooth_primes_on_the_device(planners, oracle, dt
     print(f"31-smooth Rader primes {np.dtype(dtype).name}: {len(new)} primes x 2 directions, worst rel L2 vs numpy c128 {worst:.2e}")
 
 
+def _moved_to_the_stage_machine(planner, lo, hi):
+    """Lengths in [lo, hi] that AUTO plans as the LDS stage machine (plan.cpp try_lsm: the calibrated choice)."""
+    out = []
+    for n in range(lo, hi + 1):
+        small = n
+        for q in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31):
+            while small % q == 0:
+                small //= q
+        if small == 1:
+            continue  # 31-smooth: a compiled whole-row schedule
+        if planner.plan_fft(n, 0).describe().startswith("lsm<"):
+            out.append(n)
+    return out
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_stage_machine_every_moved_length_up_to_4096(planners, oracle, dtype):
+    """Round 6: EVERY length <= 4096 that left whole-length Bluestein for the LDS stage machine (the reference's MixedRadix over the smooth
+    part and one Rader per large prime factor, src/plan.rs:412-425, 474-506; lsm.h), both directions, two full workgroups of rows and a ragged
+    one, against numpy in float64; every seventh length also element-wise against the oracle's plan of the length (tests/accuracy.rs bar)."""
+    import re
+
+    planner = planners[np.dtype(dtype)]
+    moved = _moved_to_the_stage_machine(planner, 38, 4096)
+    assert len(moved) >= (700 if dtype == np.complex64 else 300), len(moved)
+    worst = 0.0
+    for i, n in enumerate(moved):
+        for d in (0, 1):
+            fft = planner.plan_fft(n, d)
+            rows = 2 * int(re.search(r"sF(\d+)$", fft.describe()).group(1)) + 1
+            x = random_signal(rows * n, dtype, seed=n)
+            y = x.copy()
+            fft.process(y)
+            err = rel_l2(y, numpy_fft(x, n, d == 1))
+            worst = max(worst, err)
+            assert err < REL[np.dtype(dtype)], (n, d, err, fft.describe())
+            if i % 7 == 0:
+                want = x.copy()
+                oracle.plan(dtype, n, d).process(want)
+                assert compare_vectors(want, y), (n, d, fft.describe())
+    print(f"stage machine {np.dtype(dtype).name}: {len(moved)} lengths <= 4096 x 2 directions, worst rel L2 vs numpy c128 {worst:.2e}")
+
+
+@pytest.mark.parametrize("dtype", [np.complex64, np.complex128])
+def test_stage_machine_above_4096_and_host_planner_trees(planners, oracle, dtype):
+    """The stage machine above 4096 (every 29th moved length up to 16384: 512- and 1024-thread programs, six-step tables in global memory) and
+    the trees AUTO does not take but a host planner may ask for (MixedRadix / Rader requests: two Rader factors, Rader over MixedRadix over
+    Rader), device-resident at FULL occupancy (2 x 256 x F rows), all three API modes, against numpy float64 and the oracle."""
+    import re
+
+    import torch
+
+    import rustfft_amd
+
+    planner = planners[np.dtype(dtype)]
+    tdt = torch.complex64 if dtype == np.complex64 else torch.complex128
+    cases = [(n, None) for n in _moved_to_the_stage_machine(planner, 4097, 16384 if dtype == np.complex64 else 8192)[::29]]
+    assert len(cases) >= (20 if dtype == np.complex64 else 5), len(cases)
+    cases += [(1369, rustfft_amd.ALGO_MIXED_RADIX), (1517, rustfft_amd.ALGO_MIXED_RADIX), (3034, rustfft_amd.ALGO_MIXED_RADIX), (167, rustfft_amd.ALGO_RADER),
+              (1283, rustfft_amd.ALGO_RADER), (3067, rustfft_amd.ALGO_RADER)]
+    for n, algo in cases:
+        for d in (0, 1):
+            fft = planner.plan_fft(n, d) if algo is None else planner.plan_fft_with(n, d, algorithm=algo)
+            assert fft.describe().startswith("lsm<"), (n, fft.describe())
+            F = int(re.search(r"sF(\d+)$", fft.describe()).group(1))
+            rows = min(2 * 256 * F + 1, max(3, (1 << 27) // (n * np.dtype(dtype).itemsize)))
+            x = random_signal(rows * n, dtype, seed=n + d)
+            want = numpy_fft(x[: 64 * n], n, d == 1)
+            dx = torch.from_numpy(x).cuda()
+            y = dx.clone()
+            fft.process(y)  # in place, device-resident
+            out = torch.empty_like(dx)
+            fft.process_immutable_with_scratch(dx, out)
+            assert torch.equal(torch.view_as_real(out), torch.view_as_real(y)), (n, "immutable")
+            src = dx.clone()
+            out2 = torch.empty_like(dx)
+            fft.process_outofplace_with_scratch(src, out2)
+            assert torch.equal(torch.view_as_real(out2), torch.view_as_real(y)), (n, "out of place")
+            got = y.cpu().numpy()
+            assert rel_l2(got[: 64 * n], want) < REL[np.dtype(dtype)], (n, d, fft.describe())
+            # every row against the first block's rows is not possible (random rows): check the LAST rows too (the ragged workgroup)
+            tail = x[-3 * n:]
+            assert rel_l2(got[-3 * n:], numpy_fft(tail, n, d == 1)) < REL[np.dtype(dtype)], (n, d, "tail")
+            ref = x[: 2 * n].copy()
+            oracle.plan(dtype, n, d).process(ref)
+            assert compare_vectors(ref, got[: 2 * n]), (n, d, fft.describe())
+
+
 def test_repeatability_bit_for_bit(planners):
     """A transform is a pure function of its input: five runs of every kernel family on the same HBM-resident input must
     agree bit for bit.  A write-write or read-write race between threads (round 2: the Rader X[0] slot) shows up here as
@@ -671,7 +759,8 @@ def test_repeatability_bit_for_bit(planners):
                59, 1013, 1117, 2053, 4093,                           # Rader over prime-radix sub-passes (round 5: the 31-smooth primes)
                719, 1019, 4091, 4099, 7919, 10007, 65537,            # Bluestein: one kernel, split one kernel, fused multi-kernel
                289, 899, 1200, 4096, 5000, 1 << 14, 25000,           # compiled schedules incl. prime radices, whole-row split kernels
-               4836, 20449, 44100, 1 << 17, 1 << 20, 1 << 22]        # run-time scheduled, general and power-of-two column tiles
+               4836, 20449, 44100, 1 << 17, 1 << 20, 1 << 22,        # run-time scheduled, general and power-of-two column tiles
+               74, 592, 1110, 2368, 4070, 4218, 8144, 12210]         # round 6: the LDS stage machine (64 .. 1024 threads, in-place stages)
     for dtype, tdtype in ((np.complex64, torch.complex64), (np.complex128, torch.complex128)):
         planner = planners[np.dtype(dtype)]
         for n in lengths:

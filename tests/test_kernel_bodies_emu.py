@@ -264,6 +264,8 @@ def test_lengths_beyond_one_workgroup(emu_planner, oracle, dtype):
     Bluestein (5759), a product of two large primes (101 * 103 -> MixedRadix): two-kernel Bluestein here while the padded
     length fits one workgroup, the fused multi-kernel Bluestein beyond (16411, 20011); and a smooth composite
     (5000 -> RadixN there, one split-exchange kernel here)."""
+    import rustfft_amd
+
     planner = emu_planner(dtype)
     two_kernel_limit = 16384 if dtype == np.complex64 else 8192  # padded length <= 32768 (f32) / 16384 (f64) fits one workgroup
     for n in (4097, 5000, 5759, 10007, 101 * 103, 16411, 20011):
@@ -273,6 +275,10 @@ def test_lengths_beyond_one_workgroup(emu_planner, oracle, dtype):
                 assert "k1<5000" in fft.describe()
             elif n == 101 * 103:  # round 3: two prime-tile passes (Rader inside the tile) instead of the two-kernel Bluestein
                 assert fft.describe().startswith("k2rfirst<102,") and " -> k2rlater<100," in fft.describe(), fft.describe()
+            elif n == 4097:  # round 6: 17 x 241 as the reference's MixedRadix over two Rader factors, one kernel (the LDS stage machine)
+                assert fft.describe().startswith("lsm<mixed{rader241["), fft.describe()
+            elif n == 5759 and dtype == np.complex64:  # round 6: 13 x 443 (442 = 17 x 26): ten stages -- within Complex<f32>'s calibrated limit above 4096, not f64's
+                assert fft.describe().startswith("lsm<mixed{rader443["), fft.describe()
             elif n <= 8192:  # round 2: ONE kernel -- split exchange, the spectrum handed over in registers (padded length <= 16384)
                 assert fft.describe().startswith("bluestein<") and fft.describe().endswith(("s", "st1")), fft.describe()  # split exchange (+ staged tables)
             elif n <= two_kernel_limit:
@@ -294,7 +300,7 @@ def test_lengths_beyond_one_workgroup(emu_planner, oracle, dtype):
     try:
         fresh = emu_planner(dtype)
         for n in (8209, 10007):  # (lengths up to 8192 are one-kernel plans since round 2)
-            fft = fresh.plan_fft(n, 1)
+            fft = fresh.plan_fft_with(n, 1, algorithm=rustfft_amd.ALGO_BLUESTEIN)  # (round 6: AUTO plans 8209 as a Rader tree in the LDS stage machine)
             assert "bluestein_large" in fft.describe() and "fused" not in fft.describe()
             check_fft_algorithm(fft, n, 1, reference=oracle.plan(dtype, n, 1), n=2)
     finally:
@@ -318,7 +324,10 @@ def test_large_prime_rader(emu_planner, oracle, dtype):
             assert fft.describe().startswith("rader_large(p-1=%d fused: k2gfirst_gather<" % (p - 1)), fft.describe()
             assert "k2glast_rmul<" in fft.describe() and "k2glast_scatter<" in fft.describe(), fft.describe()
             check_fft_algorithm(fft, p, d, reference=oracle.plan(dtype, p, d), n=2 if p < 20000 else 1)
-    assert "bluestein" in planner.plan_fft(4481, 0).describe()  # AUTO below the threshold
+    # AUTO below the threshold: Bluestein until round 5; round 6: one Rader over a 4480-point leaf in ONE kernel (the LDS stage machine, seven stages)
+    # (Complex<f64>: the row, the leaf's tables and D do not fit the 160 KiB of a workgroup: Bluestein as before)
+    auto = planner.plan_fft(4481, 0).describe()
+    assert auto.startswith("lsm<rader4481[leaf4480(") if dtype == np.complex64 else "bluestein" in auto, auto
     # eleven rows: the gather / scatter passes run the tiles of transform g on XCD g % 8 for complete groups of eight transforms
     # and in the plain order for the rest -- both index maps in one call
     for p, algo in ((4481, rustfft_amd.ALGO_RADER), (12289, rustfft_amd.ALGO_AUTO)):
@@ -360,11 +369,15 @@ def test_prime_tile_heights(emu_planner, oracle, dtype):
             assert "k2rfirst<" in fft.describe() or "k2rlater<" in fft.describe(), fft.describe()
             assert "bluestein" not in fft.describe(), fft.describe()
             check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=2)
+    # 37 x 41, at or below 4096: until round 5 AUTO kept the one-kernel Bluestein and a host planner's MixedRadix request got two prime-tile passes
+    # through HBM; round 6: both get the reference's tree in ONE kernel (the LDS stage machine: seven stages -- within Complex<f32>'s calibrated
+    # limit for AUTO, beyond Complex<f64>'s); the prime-tile passes at this size stay reachable through an explicit six-step recipe
     n = 37 * 41
-    assert "bluestein" in planner.plan_fft(n, 0).describe()
+    auto = planner.plan_fft(n, 0).describe()
+    assert auto.startswith("lsm<mixed{rader41[") if dtype == np.complex64 else "bluestein" in auto, auto
     for d in (0, 1):
         fft = planner.plan_fft_with(n, d, algorithm=rustfft_amd.ALGO_MIXED_RADIX)
-        assert fft.describe().startswith("k2rfirst<") and " -> k2rlater<" in fft.describe(), fft.describe()
+        assert fft.describe().startswith("lsm<mixed{rader41[leaf40("), fft.describe()
         check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=3)
 
 
@@ -422,11 +435,9 @@ def test_runtime_scheduled_kernels(emu_planner, oracle, dtype):
 
     for p in primes:  # MI355FFT_ALGO_RADER: the host planner's Recipe::RadersAlgorithm -> run-time scheduled Rader
         for d in (0, 1):
-            if not smooth13(p - 1):  # the inner length must run as one mixed-radix workgroup transform
-                with pytest.raises(rustfft_amd.FftPanic, match="no GPU plan"):
-                    planner.plan_fft_with(p, d, algorithm=rustfft_amd.ALGO_RADER)
-                continue
             fft = planner.plan_fft_with(p, d, algorithm=rustfft_amd.ALGO_RADER)
+            if not smooth13(p - 1):  # round 6: Rader over MixedRadix over Rader, the reference's recursion (src/plan.rs:636-665), in the LDS stage machine
+                assert fft.describe().startswith("lsm<rader%d[mixed{rader" % p), (p, fft.describe())
             assert "rader" in fft.describe(), (p, fft.describe())
             check_fft_algorithm(fft, p, d, reference=oracle.plan(dtype, p, d), n=3)
 
