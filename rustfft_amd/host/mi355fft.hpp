@@ -86,6 +86,9 @@ template <class T> class Fft {
     void process_immutable_device(const void* input, void* output, std::size_t batch, void* stream = nullptr) const {
         detail::check(mi355fft_process_immutable_dev(plan_, input, output, batch, stream));
     }
+    // waits for `stream` and throws if a fused launch of this plan on it gave up a dependency wait: the verdict the asynchronous device
+    // calls above cannot return themselves (mi355fft_plan_synchronize; src/lib.rs:184: an Fft is never silently wrong)
+    void synchronize(void* stream = nullptr) const { detail::check(mi355fft_plan_synchronize(plan_, stream)); }
     // what the plan took from options.recipe (MI355FFT_RECIPE_STATUS_*)
     int recipe_status() const { return mi355fft_plan_recipe_status(plan_); }
     std::string describe() const {

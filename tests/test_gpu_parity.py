@@ -896,11 +896,14 @@ def test_prime_tile_heights_vs_oracle(planners, oracle, dtype):
             y = x.copy()
             fft.process(y)
             assert rel_l2(y, numpy_fft(x, n, d == 1)) < REL[np.dtype(dtype)], (n, d, fft.describe())
+    # at or below 4096: until round 5 AUTO kept the one-kernel Bluestein and a MixedRadix request got two prime-tile passes through HBM; round 6: the
+    # reference's tree in ONE kernel (the LDS stage machine: seven stages -- AUTO's calibrated limit in Complex<f32>, one beyond Complex<f64>'s)
     for n in (37 * 41, 59 * 61):
-        assert "bluestein" in planner.plan_fft(n, 0).describe()
+        auto = planner.plan_fft(n, 0).describe()
+        assert auto.startswith("lsm<mixed{rader") if dtype == np.complex64 else "bluestein" in auto, auto
         for d in (0, 1):
             fft = planner.plan_fft_with(n, d, algorithm=rustfft_amd.ALGO_MIXED_RADIX)
-            assert fft.describe().startswith("k2rfirst<") and " -> k2rlater<" in fft.describe(), fft.describe()
+            assert fft.describe().startswith("lsm<mixed{rader"), fft.describe()
             check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=3)
 
 

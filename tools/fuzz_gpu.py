@@ -32,6 +32,17 @@ def main():
                     break
                 n *= p
             n = max(n, 2)
+        if os.environ.get("FUZZ_ROUND6") == "1":
+            # round-6 plans: lengths up to 16384 with a prime factor above 31 -- the LDS stage machine where the planner takes it (short trees),
+            # Bluestein where it does not
+            while True:
+                n = int(np.exp(rng.uniform(np.log(38), np.log(16384))))
+                m = n
+                for q in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31):
+                    while m % q == 0:
+                        m //= q
+                if m > 1:
+                    break
         if os.environ.get("FUZZ_ROUND3") == "1":
             # round-3 plans: composites with prime factors 37 .. 631 (prime tile heights), primes above 8192 with 13-smooth p - 1
             # (multi-kernel Rader), the small primes served by the side-by-side Rader bodies (batched loads)
