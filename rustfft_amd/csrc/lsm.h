@@ -39,7 +39,9 @@ enum LsmFlag {
     LSM_TW_PRE = 1,      // multiply input k by w^(row k) before the butterfly (decimation in time)
     LSM_TW_POST = 2,     // multiply output k by w^(row k) after it (decimation in frequency)
     LSM_PRE_MUL = 4,     // multiply every input by a table entry first
-    LSM_PRE_GLOBAL = 8   // ... whose table lives in global memory (LsmParams::gtab) instead of LDS
+    LSM_PRE_GLOBAL = 8,  // ... whose table lives in global memory (LsmParams::gtab) instead of LDS
+    LSM_PRE2 = 16        // BFLY2: a second table multiplies the INPUTS (a six-step twiddle in front of Rader's middle stage): index = the spectrum
+                         // multiplier's + p2_delta, in LDS or (LSM_PRE_GLOBAL) in global memory; the spectrum multiplier itself is always in LDS
 };
 
 struct LsmStage {
@@ -52,6 +54,7 @@ struct LsmStage {
     int pdesc_off;  // first pre-multiplier index of the stage (stages with LSM_PRE_MUL)
     float cfix;     // FIX / BFLY2: S[0] += cfix * x[0]   (= -(q - 1): 1 / D[0], lsm_plan.h)
     int fix_off;    // BFLY2: slot of x[0] relative to the base of the item that holds S[0] (bit 31 of its pre-multiplier word marks that item)
+    int p2_delta;   // BFLY2 with LSM_PRE2: index of the input table = index of the spectrum multiplier + p2_delta
     int round;      // work items the workgroup takes per ROUND: NT x the items a thread holds at this radix; a stage with more runs several rounds
 };
 
@@ -191,6 +194,19 @@ MI_HD void lsm_bfly2(const LsmStage& st, const LsmParams<T>& p, int tid, cx<T>* 
         if (j * NT < total && tid + j * NT < total) {
             const int base = (int)(dw[j] & 0xffffu), tr = (int)(dw[j] >> 16), pi = (int)(dp[j] & 0x7fffffffu);
             cx<T>* x = v + j * R;
+            if (flags & LSM_PRE2) {
+                if (flags & LSM_PRE_GLOBAL) {
+                    static_for<0, R>([&](auto K_) {
+                        constexpr int k = K_;
+                        x[k] = x[k] * p.gtab[(unsigned)(pi + st.p2_delta + k * st.p_kstep)];
+                    });
+                } else {
+                    static_for<0, R>([&](auto K_) {
+                        constexpr int k = K_;
+                        x[k] = x[k] * ltab[pi + st.p2_delta + k * st.p_kstep];
+                    });
+                }
+            }
             if (has_tw) {
                 if (!AHEAD) load_tw(j * R, tr);
                 static_for<1, R>([&](auto K_) {

@@ -9,24 +9,25 @@ namespace mi355 {
 constexpr int KIND_LSM = 22;  // registry.h KernelKind continues here
 
 #if !defined(MI355_EMU)
-template <class T> struct LsmDevExec {
+template <class T, int NT> struct LsmDevExec {
     unsigned w[4 * kLsmItems];
     template <class Fn> __device__ __forceinline__ void for_threads(Fn&& fn) { fn((int)threadIdx.x, (cx<T>*)nullptr); }
     __device__ __forceinline__ unsigned* words(int) { return w; }
     __device__ __forceinline__ void barrier() { __syncthreads(); }
 };
 // four waves per SIMD (128 VGPRs) is what hides the LDS round trips and the barriers of a program whose stages are short
-// Waves per SIMD the register allocator is asked for: FOUR for Complex<f32> (128 VGPRs: the radix-16 stage spills 19 registers, everything else
-// fits) and THREE for Complex<f64> (168 VGPRs, 35 spilled) instead of the 142 / 183 VGPRs the kernels take when left alone.  The stages are
-// short and separated by barriers, so resident waves are what hides their LDS round trips: measured with one build against the other
-// (profiles/r6/lsm_w4_ab_f32.jsonl): 512-thread programs x1.35 .. x1.66 (one workgroup per CU -> two), 64- / 128-thread programs x1.14 ..
-// x1.19, 256-thread programs 0.90 .. 1.20.
+// Waves per SIMD the register allocator is asked for: FOUR for Complex<f32> (the unit is compiled without the SLP vectoriser -- Makefile NOSLP:
+// 115 VGPRs, nothing spilled; with it 142 VGPRs left alone, 19 spilled at 128) and TWO for Complex<f64> (183 VGPRs, nothing spilled).  The stages
+// are short and separated by barriers, so resident waves are what hides their LDS round trips -- but a SPILL costs more than a wave buys:
+// measured with one build against the other, Complex<f32> 128 against 142 VGPRs: 512-thread programs x1.35 .. x1.66, 64- / 128-thread x1.14 ..
+// x1.19 (profiles/r6/lsm_w4_ab_f32.jsonl); Complex<f64> at three waves (168 VGPRs, 46 spilled) against two: the two-wave build x1.07 .. x1.40 at
+// 17 of 17 lengths (profiles/r6/lsm_w2_ab_f64.jsonl).
 #if !defined(MI355_LSM_WAVES)
-#define MI355_LSM_WAVES(T) (sizeof(T) == 4 ? 4 : 3)
+#define MI355_LSM_WAVES(T) (sizeof(T) == 4 ? 4 : 2)
 #endif
 template <class T, int NT> __global__ __launch_bounds__(NT, MI355_LSM_WAVES(T)) void lsm_kernel(LsmParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    LsmDevExec<T> ex;
+    LsmDevExec<T, NT> ex;
     lsm_body<T, NT>(ex, p, (long long)blockIdx.x, smem);
 }
 template <class T> const void* lsm_fn(int nt) {

@@ -57,7 +57,7 @@ struct HostStage {
     std::vector<int> n, a, t, p;  // digit 0 fastest
     std::vector<int> inner;       // 1: a digit of the transform itself (its value is 0 in the item that holds element 0), 0: a batch digit
     bool fix = false;             // BFLY2: the item whose inner digits are all 0 does the x[0] step
-    int fix_off = 0;
+    int fix_off = 0, p2_delta = 0, fix_s0 = 0;  // fix_s0: in-row slot of S[0] relative to the instance (the item whose base it is does the x[0] step)
     int abase = 0, astep = 0, tw_off = 0, tw_kstep = 0, p_off = 0, p_kstep = 0;
     float cfix = 0;
 };
@@ -421,10 +421,14 @@ struct Emitter {
         }
         HostStage& A = prog->hstages[last1];
         const HostStage& B = second.front();
+        // (the forward stage may carry a pre-multiplier of its own when it is ALSO the first stage of its transform -- a one-stage leaf behind a
+        // six-step twiddle, the shape of every prime whose p - 1 = m q with m <= 16: both tables are laid out by the slots of the same node, so
+        // one index serves both up to a constant)
+        const bool a_pre = (A.flags & LSM_PRE_MUL) != 0;
         const bool mirror = fuse && A.op == LSM_BFLY && B.op == LSM_BFLY && A.radix == B.radix && A.n == B.n && A.a == B.a && A.t == B.t && A.abase == B.abase &&
                             A.astep == B.astep && A.tw_kstep == B.tw_kstep && ((A.flags & LSM_TW_PRE) != 0) == ((B.flags & LSM_TW_POST) != 0) &&
-                            (!(A.flags & LSM_TW_PRE) || A.tw_off == B.tw_off) && !(A.flags & LSM_PRE_MUL) && (B.flags & LSM_PRE_MUL) && !(B.flags & LSM_PRE_GLOBAL) &&
-                            s0 == fr.base;
+                            (!(A.flags & LSM_TW_PRE) || A.tw_off == B.tw_off) && (B.flags & LSM_PRE_MUL) && !(B.flags & LSM_PRE_GLOBAL) &&
+                            (!a_pre || (A.p == B.p && A.p_kstep == B.p_kstep));
         auto batch_digs = [&]() {
             std::vector<Dig> digs;
             for (size_t b = 0; b < fr.batch.size(); ++b) digs.push_back(Dig{fr.batch[b].n, fr.batch[b].stride, 0, pstride(pre, fr.batch[b].stride, (int)b < pre.n_outer), 0});
@@ -436,12 +440,14 @@ struct Emitter {
             // x[0] has not met an incoming pre-multiplier yet: the first inner transform's first stage took it for the other q - 1 inputs
             if (pre.on) push_stage(LSM_X0MUL, 1, 0, x0, 0, batch_digs(), 0, 0, pre, pre.tab_off + (x0 - pre.base) / pre.sigma, 0, 0.f);
             fused.op = LSM_BFLY2;
-            fused.flags = (fused.flags & LSM_TW_PRE) | LSM_PRE_MUL;
+            fused.p2_delta = a_pre ? fused.p_off - B.p_off : 0;
+            fused.flags = (fused.flags & LSM_TW_PRE) | LSM_PRE_MUL | (a_pre ? (LSM_PRE2 | (fused.flags & LSM_PRE_GLOBAL)) : 0);
             fused.p = B.p;
             fused.p_off = B.p_off;
             fused.p_kstep = B.p_kstep;
             fused.fix = true;
             fused.fix_off = x0 - s0;
+            fused.fix_s0 = s0 - fr.base;
             fused.cfix = -(float)L;
             prog->hstages.push_back(fused);
             for (size_t i = 1; i < second.size(); ++i) prog->hstages.push_back(second[i]);
@@ -559,21 +565,22 @@ inline bool finish(Program& prog, int esz) {
         st.p_kstep = h.p_kstep;
         st.cfix = h.cfix;
         st.fix_off = h.fix_off;
+        st.p2_delta = h.p2_delta;
         st.round = prog.nt * ((h.op == LSM_BFLY || h.op == LSM_BFLY2) ? items_per_thread(h.radix) : kLsmItems);
         std::vector<unsigned> dw, pd;
         for (int f = 0; f < F; ++f)
             for (int i = 0; i < h.items; ++i) {
                 int rem = i, base = h.abase + f * prog.rp, tr = h.tw_off, pi = h.p_off;
-                bool zero = true;  // every digit of the transform itself is 0: the item that holds element 0
+                int rel = 0;  // the item's base relative to its Rader instance: S[0] sits at a known slot of the instance
                 for (size_t d = 0; d < h.n.size(); ++d) {
                     const int dig = rem % h.n[d];
                     rem /= h.n[d];
                     base += dig * h.a[d];
                     tr += dig * h.t[d];
                     pi += dig * h.p[d];
-                    if (h.inner[d] && dig != 0) zero = false;
+                    if (h.inner[d] || h.p[d] != 0) rel += dig * h.a[d];  // (digits inside the instance: the transform's own and the batch digits its tables are indexed by)
                 }
-                if (h.fix && zero) pi |= (int)0x80000000u;
+                if (h.fix && rel == h.fix_s0) pi |= (int)0x80000000u;
                 if (base < 0 || base > 65535 || tr < 0 || tr > 65535) return false;
                 dw.push_back((unsigned)base | ((unsigned)tr << 16));
                 if (h.flags & LSM_PRE_MUL) pd.push_back((unsigned)pi);

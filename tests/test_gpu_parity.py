@@ -685,7 +685,7 @@ def test_stage_machine_every_moved_length_up_to_4096(planners, oracle, dtype):
 
     planner = planners[np.dtype(dtype)]
     moved = _moved_to_the_stage_machine(planner, 38, 4096)
-    assert len(moved) >= (700 if dtype == np.complex64 else 300), len(moved)
+    assert len(moved) >= (1200 if dtype == np.complex64 else 1000), len(moved)
     worst = 0.0
     for i, n in enumerate(moved):
         for d in (0, 1):
@@ -897,10 +897,10 @@ def test_prime_tile_heights_vs_oracle(planners, oracle, dtype):
             fft.process(y)
             assert rel_l2(y, numpy_fft(x, n, d == 1)) < REL[np.dtype(dtype)], (n, d, fft.describe())
     # at or below 4096: until round 5 AUTO kept the one-kernel Bluestein and a MixedRadix request got two prime-tile passes through HBM; round 6: the
-    # reference's tree in ONE kernel (the LDS stage machine: seven stages -- AUTO's calibrated limit in Complex<f32>, one beyond Complex<f64>'s)
+    # reference's tree in ONE kernel (the LDS stage machine: seven stages, within AUTO's calibrated limit in both precisions)
     for n in (37 * 41, 59 * 61):
         auto = planner.plan_fft(n, 0).describe()
-        assert auto.startswith("lsm<mixed{rader") if dtype == np.complex64 else "bluestein" in auto, auto
+        assert auto.startswith("lsm<mixed{rader"), auto
         for d in (0, 1):
             fft = planner.plan_fft_with(n, d, algorithm=rustfft_amd.ALGO_MIXED_RADIX)
             assert fft.describe().startswith("lsm<mixed{rader"), fft.describe()

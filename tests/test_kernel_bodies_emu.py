@@ -277,7 +277,7 @@ def test_lengths_beyond_one_workgroup(emu_planner, oracle, dtype):
                 assert fft.describe().startswith("k2rfirst<102,") and " -> k2rlater<100," in fft.describe(), fft.describe()
             elif n == 4097:  # round 6: 17 x 241 as the reference's MixedRadix over two Rader factors, one kernel (the LDS stage machine)
                 assert fft.describe().startswith("lsm<mixed{rader241["), fft.describe()
-            elif n == 5759 and dtype == np.complex64:  # round 6: 13 x 443 (442 = 17 x 26): ten stages -- within Complex<f32>'s calibrated limit above 4096, not f64's
+            elif n == 5759:  # round 6: 13 x 443 (442 = 17 x 26): ten stages -- within the calibrated limit of both precisions above 4096
                 assert fft.describe().startswith("lsm<mixed{rader443["), fft.describe()
             elif n <= 8192:  # round 2: ONE kernel -- split exchange, the spectrum handed over in registers (padded length <= 16384)
                 assert fft.describe().startswith("bluestein<") and fft.describe().endswith(("s", "st1")), fft.describe()  # split exchange (+ staged tables)
@@ -370,11 +370,11 @@ def test_prime_tile_heights(emu_planner, oracle, dtype):
             assert "bluestein" not in fft.describe(), fft.describe()
             check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=2)
     # 37 x 41, at or below 4096: until round 5 AUTO kept the one-kernel Bluestein and a host planner's MixedRadix request got two prime-tile passes
-    # through HBM; round 6: both get the reference's tree in ONE kernel (the LDS stage machine: seven stages -- within Complex<f32>'s calibrated
-    # limit for AUTO, beyond Complex<f64>'s); the prime-tile passes at this size stay reachable through an explicit six-step recipe
+    # through HBM; round 6: both get the reference's tree in ONE kernel (the LDS stage machine: seven stages -- within AUTO's calibrated limit
+    # in both precisions); the prime-tile passes at this size stay reachable through an explicit six-step recipe
     n = 37 * 41
     auto = planner.plan_fft(n, 0).describe()
-    assert auto.startswith("lsm<mixed{rader41[") if dtype == np.complex64 else "bluestein" in auto, auto
+    assert auto.startswith("lsm<mixed{rader41["), auto
     for d in (0, 1):
         fft = planner.plan_fft_with(n, d, algorithm=rustfft_amd.ALGO_MIXED_RADIX)
         assert fft.describe().startswith("lsm<mixed{rader41[leaf40("), fft.describe()
