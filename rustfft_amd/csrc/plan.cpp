@@ -957,11 +957,12 @@ template <class T> static int build_plan_t(Plan& plan) {
         // AUTO takes the program where it beat the Bluestein plan of the length in an on-device A/B over 400 random lengths per precision
         // (profiles/r6/lsm_calib_*.jsonl, tools/r6_lsm_calib_report.py), by program length -- the one-kernel Bluestein it competes with up to
         // 4096 runs 1.7 - 2.6 TB/s, the split-exchange and two-kernel forms above it 0.5 - 1.2:
-        //   Complex<f32>: <= 9 stages up to 4096 (medians x1.58, x1.70, x1.34, x1.37, x1.13, x1.13 at 4 .. 9 stages; 10: x0.95), <= 13 up to 8192
-        //                 (x1.16 .. x2.5; 15: x1.01), <= 14 above (x1.2 .. x2.9; 15: x0.99)
-        //   Complex<f64>: <= 7 stages up to 4096 (x1.35, x1.57, x1.31, x1.25 at 4 .. 7; 8: x1.02 with 5 wins of 10), <= 10 up to 8192 (x1.09 .. x1.47;
-        //                 11: x0.98), <= 14 above (x1.9 .. x2.6)
-        const int calibrated = sizeof(T) == 4 ? (n <= 4096 ? 9 : n <= 8192 ? 13 : 14) : (n <= 4096 ? 7 : n <= 8192 ? 10 : 14);
+        //   Complex<f32>: up to 1800 (one-kernel Bluestein at 2.0 - 2.8 TB/s) <= 7 stages (medians x1.54, x1.69, x1.32, x1.07 at 4 .. 7; 8: x0.82);
+        //                 1800 .. 4096 (Bluestein 1.4 - 1.8) <= 9 (x1.38, x1.14, x1.05 at 7 .. 9; 10: x0.92); <= 9 up to 8192 (x1.5 .. x2.5; 10: x0.96);
+        //                 <= 13 above (x1.3 .. x2.9)
+        //   Complex<f64>: up to 1800 <= 7 (x1.30, x1.56, x1.28, x1.03); 1800 .. 4096 <= 8 (x1.25, x1.07 at 7, 8; 9: x0.96); <= 9 up to 8192
+        //                 (x1.15 .. x1.39); <= 13 above (x2.0 .. x2.5)
+        const int calibrated = sizeof(T) == 4 ? (n <= 1800 ? 7 : n <= 4096 ? 9 : n <= 8192 ? 9 : 13) : (n <= 1800 ? 7 : n <= 4096 ? 8 : n <= 8192 ? 9 : 13);
         const int max_stages = env_int("MI355FFT_LSM_MAX_STAGES") ? env_int("MI355FFT_LSM_MAX_STAGES") : calibrated;
         if (have && ((int)best.stages.size() <= max_stages || always)) {
             if (lk->prepare()) return -MI355FFT_ERR_HIP;
