@@ -936,7 +936,7 @@ template <class T> static int build_plan_t(Plan& plan) {
     // planned inner length (src/plan.rs:412-425, 474-506, 636-665) -- as ONE kernel from a run-time program.  A host planner's
     // MixedRadix (composite) / Rader (prime) request gets it too.
     // Returns 1 when the plan was made, 0 when this length is not taken, an error otherwise.  `always`: whatever the program costs.
-    auto try_lsm = [&](bool always) -> int {
+    auto try_lsm = [&](bool always, int cap = 1 << 20) -> int {
         if (algo == MI355FFT_ALGO_BLUESTEIN || n > 16384 || plan.opt_rader || env_int("MI355FFT_NO_LSM") != 0) return 0;  // (a host planner's finished Rader table is in the reference's form: the compiled / run-time Rader bodies take it)
         lsm::Hooks hooks;
         hooks.tw = [](size_t i, size_t len) {
@@ -963,7 +963,7 @@ template <class T> static int build_plan_t(Plan& plan) {
         //   Complex<f64>: up to 1800 <= 7 (x1.30, x1.56, x1.28, x1.03); 1800 .. 4096 <= 8 (x1.25, x1.07 at 7, 8; 9: x0.96); <= 9 up to 8192
         //                 (x1.15 .. x1.39); <= 13 above (x2.0 .. x2.5)
         const int calibrated = sizeof(T) == 4 ? (n <= 1800 ? 7 : n <= 4096 ? 9 : n <= 8192 ? 9 : 13) : (n <= 1800 ? 7 : n <= 4096 ? 8 : n <= 8192 ? 9 : 13);
-        const int max_stages = env_int("MI355FFT_LSM_MAX_STAGES") ? env_int("MI355FFT_LSM_MAX_STAGES") : calibrated;
+        const int max_stages = env_int("MI355FFT_LSM_MAX_STAGES") ? env_int("MI355FFT_LSM_MAX_STAGES") : (calibrated < cap ? calibrated : cap);
         if (have && ((int)best.stages.size() <= max_stages || always)) {
             if (lk->prepare()) return -MI355FFT_ERR_HIP;
             plan.kind = PLAN_SINGLE;
@@ -1074,8 +1074,18 @@ template <class T> static int build_plan_t(Plan& plan) {
         // gets it whatever it costs, AUTO where its program is short (measured against the one-kernel Bluestein: profiles/r6/lsm_vs_bluestein_*.jsonl)
         bool rader_body = false;  // (a compiled Rader body -- the primes <= 4096 with 31-smooth p - 1 -- is faster than the stage machine's Rader)
         for (auto& e0 : registry()) rader_body = rader_body || (e0.kind == KIND_RADER && e0.prec == plan.prec && (size_t)e0.aux == n && e0.variant == 0);
-        if (n <= 4096 && !rader_body) {
-            const int r = try_lsm(algo == MI355FFT_ALGO_MIXED_RADIX);
+        if (!rader_body) {
+            // Above 4096 the competitor in front of Bluestein is a two- or three-pass plan over general / prime tile heights (1.2 - 1.9 TB/s: every
+            // element crosses HBM four or six times): the stage machine goes first where its program is short enough to beat THAT -- measured with
+            // a build that always prefers it against the shipped order, 160 random lengths with a prime factor 37 .. 631 per precision
+            // (profiles/r6/lsm_vs_tiles_*.jsonl): Complex<f32> x1.50 / x1.83 at 5 / 7 stages up to 8192, x1.07 .. x1.15 at 5 .. 7 above (10: x0.91);
+            // Complex<f64> x1.07 / x1.32 up to 8192, x1.08 .. x1.19 at 5 .. 7 above (9: x0.85)
+#if defined(MI355_LSM_FIRST)  // (that measurement build)
+            const int cap = 1 << 20;
+#else
+            const int cap = n <= 4096 ? (1 << 20) : 7;
+#endif
+            const int r = try_lsm(algo == MI355FFT_ALGO_MIXED_RADIX && n <= 4096, cap);
             if (r < 0) return -r;
             if (r > 0) return MI355FFT_OK;
         }
