@@ -1078,12 +1078,12 @@ template <class T> static int build_plan_t(Plan& plan) {
             // Above 4096 the competitor in front of Bluestein is a two- or three-pass plan over general / prime tile heights (1.2 - 1.9 TB/s: every
             // element crosses HBM four or six times): the stage machine goes first where its program is short enough to beat THAT -- measured with
             // a build that always prefers it against the shipped order, 160 random lengths with a prime factor 37 .. 631 per precision
-            // (profiles/r6/lsm_vs_tiles_*.jsonl): Complex<f32> x1.50 / x1.83 at 5 / 7 stages up to 8192, x1.07 .. x1.15 at 5 .. 7 above (10: x0.91);
-            // Complex<f64> x1.07 / x1.32 up to 8192, x1.08 .. x1.19 at 5 .. 7 above (9: x0.85)
+            // (profiles/r6/lsm_vs_tiles_*.jsonl): Complex<f32> x1.50 / x1.83 at 5 / 7 stages up to 8192 (every one of 20 lengths wins), x1.07 .. x1.15 at
+            // 5 .. 7 above (21 wins of 27); Complex<f64> x1.07 / x1.32 up to 8192, x1.08 .. x1.19 at 5 .. 7 above
 #if defined(MI355_LSM_FIRST)  // (that measurement build)
             const int cap = 1 << 20;
 #else
-            const int cap = n <= 4096 ? (1 << 20) : 7;
+            const int cap = n <= 4096 ? (1 << 20) : n <= 8192 ? 7 : 0;  // (above 8192 the gain is x1.07 .. x1.15 in the median with losers -- 9990: 1.35 against 1.68 TB/s -- the passes stay first)
 #endif
             const int r = try_lsm(algo == MI355FFT_ALGO_MIXED_RADIX && n <= 4096, cap);
             if (r < 0) return -r;

@@ -890,8 +890,8 @@ def test_prime_tile_heights_vs_oracle(planners, oracle, dtype):
     for n in (101 * 103, 64 * 131, 37 * 41 * 43, 47 * 229, 89 * 97, 251 * 631):
         for d in (0, 1):
             fft = planner.plan_fft(n, d)
-            # (round 6: 64 x 131 and 89 x 97 are short trees and run in ONE kernel, the LDS stage machine, ahead of the two prime-tile passes)
-            assert (fft.describe().startswith("lsm<mixed{rader") if n in (64 * 131, 89 * 97) else ("k2rfirst<" in fft.describe() or "k2rlater<" in fft.describe())) and "bluestein" not in fft.describe(), fft.describe()
+            # (round 6: the LDS stage machine goes ahead of the prime-tile passes only up to 8192; these lengths keep the passes)
+            assert ("k2rfirst<" in fft.describe() or "k2rlater<" in fft.describe()) and "bluestein" not in fft.describe(), fft.describe()
             check_fft_algorithm(fft, n, d, reference=oracle.plan(dtype, n, d), n=2)
             x = zero_mean_signal(n * 3, dtype, seed=n)
             y = x.copy()
